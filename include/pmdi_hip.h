@@ -1,0 +1,179 @@
+/*
+ * pmdi_hip.h -- C ABI of libpmdi_hip.so, the MI355X (gfx950) implementation
+ * of ParticleMDI's per-Gibbs-iteration conditional-SMC sweep.
+ *
+ * The reference (pure Julia) has no FFI and no function seam around this
+ * path: it is a block inside pmdi() (src/pmdi.jl:164-384).  Each entry point
+ * below names the reference lines it replaces; INTEGRATION.md shows the
+ * `ccall` stubs a maintainer would add to src/pmdi.jl to bind them.
+ *
+ * Conventions (the reference's, so that Julia arrays pass through as-is):
+ *   - matrices are column-major; labels, cluster ids, particle and
+ *     observation indices are 1-based Int64; reals are Float64
+ *   - every function returns 0 on success or a negative PMDI_E_* code;
+ *     pmdi_last_error() returns a message for the calling thread
+ *   - no callbacks, no exceptions across the ABI, no global state: one handle
+ *     = a batch of independent chains on one device and one HIP stream;
+ *     a handle is not thread-safe, distinct handles are independent
+ *   - the library never returns memory the caller must free, and keeps no
+ *     pointer to caller memory after a call returns (data are copied to the
+ *     device once, in pmdi_create)
+ *   - there is NO CPU fallback: without a usable gfx950 device pmdi_create
+ *     fails with PMDI_E_DEVICE.
+ */
+#ifndef PMDI_HIP_H
+#define PMDI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMDI_ABI_VERSION 1
+#define PMDI_KMAX 8 /* datasets per handle */
+
+/* dataTypes[k] of pmdi(): GaussianCluster (src/datatypes/gaussian_cluster.jl),
+ * CategoricalCluster (categorical_cluster.jl), NegBinomCluster (negbinom_cluster.jl) */
+enum { PMDI_GAUSSIAN = 0, PMDI_CATEGORICAL = 1, PMDI_NEGBINOM = 2 };
+
+enum {
+    PMDI_OK = 0,
+    PMDI_E_ARG = -1,      /* an @assert of src/pmdi.jl:50-55 would have fired, or bad pointer */
+    PMDI_E_DEVICE = -2,   /* no gfx950 device / HIP error */
+    PMDI_E_MEMORY = -3,
+    PMDI_E_POOL = -4,     /* cluster pool capacity exceeded (only if pool_cap < N*P+1) */
+    PMDI_E_DATA = -5,     /* categorical level < 1, negative count, label outside 1..N */
+    PMDI_E_STATE = -6
+};
+
+/* dataFiles[k]: an n x D column-major matrix with leading dimension ld >= n
+ * (src/pmdi.jl:42-43).  Gaussian: Float64 (xf).  Categorical: Int64 levels
+ * 1..L.  NegBinom: Int64 counts >= 0 (xi). */
+typedef struct {
+    int32_t kind;
+    int32_t D;
+    int64_t ld;
+    const double  *xf;
+    const int64_t *xi;
+} pmdi_dataset;
+
+typedef struct {
+    int32_t abi_version;   /* PMDI_ABI_VERSION */
+    int32_t device;        /* HIP device ordinal */
+    int32_t K;             /* length(dataFiles)          src/pmdi.jl:42 */
+    int32_t N;             /* max clusters               src/pmdi.jl:36 */
+    int32_t P;             /* particles                  src/pmdi.jl:36 */
+    int32_t n_chains;      /* independent chains swept per call (>= 1) */
+    int64_t n;             /* n_obs                      src/pmdi.jl:43 */
+    uint64_t seed;         /* chain c uses seed + c */
+    int32_t q1_mode;       /* 0 reference: new_id zeroed per iteration (src/pmdi.jl:167); 1: per step */
+    int32_t q2_mode;       /* 0 pmdi(): history not permuted on resample (src/pmdi.jl:321-324); 1 __pmdi() (src/__pmdi.jl:285) */
+    int64_t pool_cap;      /* cluster pool ids per dataset; 0 = N*P+1 (src/pmdi.jl:140) */
+    int32_t block_threads; /* 0 = choose; else 256/512/1024 */
+    int32_t reserved;
+} pmdi_config;
+
+typedef struct pmdi_handle pmdi_handle;
+
+/* Per-chain counters of the last sweep. */
+typedef struct {
+    int64_t n_operations;  /* calc_logprob evaluations as counted by src/__pmdi.jl:187 */
+    int64_t n_resamples;   /* src/pmdi.jl:317 taken */
+    int64_t n_clones;      /* deepcopy at src/pmdi.jl:297 */
+    int64_t max_id;        /* largest pool id live during the sweep */
+    int64_t sum_classes;   /* mutation CDFs computed (fprob_done misses, src/pmdi.jl:231) */
+    int64_t reserved[3];
+} pmdi_sweep_stats;
+
+/* Replaces the allocations of src/pmdi.jl:99-146 and the null-cluster
+ * marginal of :120-128.  Copies the data to the device (row-major). */
+int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handle **out);
+int pmdi_destroy(pmdi_handle *h);
+const char *pmdi_last_error(void);
+int pmdi_abi_version(void);
+
+/* One Gibbs iteration's sweep for every chain of the handle: replaces
+ * src/pmdi.jl:165-171 (reset), :188-207 (known prefix), :209-342 (sweep with
+ * calc_logprob, allocation draw, copy-on-write cluster_add!, Phi_upweight!,
+ * calc_ESS, draw_partstar, renumbering), :345-350 (particle pick) and :373.
+ * The shuffle!(order_obs) of :172 and the hyper-parameter updates of
+ * :176-185 stay with the caller.
+ *
+ * All arrays are per chain, chain-major (chain c at base + c*size):
+ *   iter        1-based Gibbs iteration (keys the counter-based RNG)
+ *   s_in        n x K Int64 (labels 1..N)                [n*K per chain]
+ *   order_obs   n Int64, a permutation of 1..n            [n]
+ *   n1          floor(rho*n) >= 1                         (src/pmdi.jl:161)
+ *   Pi          N x K Float64 = gamma ./ sum(gamma)       [N*K]  (:179)
+ *   Phi         max(1, K(K-1)/2) Float64                  (:61)
+ *   feature_flag  sum_k D_k bytes (0/1), dataset-major; NULL = all on (:106-110)
+ *   lw_init     initial log-weight: 0.0 on the first iteration, 1.0 after (:99,:372)
+ * outputs (any may be NULL):
+ *   s_out       n x K Int64 = sstar[p_star,:,:]           (:373)
+ *   logweight   P Float64                                  (:99)
+ *   p_star      Int64 1-based                              (:350)
+ *   stats       pmdi_sweep_stats
+ *   trace       (n-n1+1) x (2+2K) Float64 row-major per chain:
+ *               [ESS, resampled, max id per k, classes per k] per swept obs
+ */
+int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t *order_obs,
+               int64_t n1, const double *Pi, const double *Phi, const uint8_t *feature_flag,
+               double lw_init, int64_t *s_out, double *logweight, int64_t *p_star,
+               pmdi_sweep_stats *stats, double *trace);
+
+/* The same sweep on buffers already resident on the handle's device, launched
+ * asynchronously on `stream` (a hipStream_t; NULL = the handle's stream).
+ * Internal encodings (no conversion pass): labels and indices 0-based int32,
+ *   s_in/s_out [chain][K][n], order_obs [chain][n], Pi [chain][K][N],
+ *   log1p_phi [chain][max(1,K(K-1)/2)] = log(1+Phi), feature_flag as above,
+ *   p_star int32 0-based, stats int64[8] per chain.  err: int32 per chain. */
+int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const int32_t *order_obs,
+                      int64_t n1, const double *Pi, const double *log1p_phi,
+                      const uint8_t *feature_flag, double lw_init, int32_t *s_out,
+                      double *logweight, int32_t *p_star, int64_t *stats, int32_t *err,
+                      void *stream);
+
+/* Feature selection for the trajectories chosen by the last sweep:
+ * replaces src/pmdi.jl:354-370 (calc_logmarginal of every occupied cluster
+ * rebuilt from all n rows, plus the null marginal of :120-128 computed in
+ * pmdi_create).  s_traj: n x K Int64 per chain (normally s_out).  Outputs
+ * per chain: feature_flag sum_k D_k bytes, feature_prob sum_k D_k Float64. */
+int pmdi_feature_select(pmdi_handle *h, int64_t iter, const int64_t *s_traj,
+                        uint8_t *feature_flag, double *feature_prob);
+
+/* Debug export of the SMC state after the last sweep, in the shapes returned
+ * by __pmdi() (src/__pmdi.jl:342) so that the invariants of
+ * test/runtests.jl:147-162 can be run on the device path.  Per chain:
+ *   particle  N x P x K Int64 (cluster ids)      counts   pool_cap x K Int64
+ *   cluster_n pool_cap x K Int64 (cl.n per id)   max_id   K Int64 */
+int pmdi_export_state(pmdi_handle *h, int32_t chain, int64_t *particle, int64_t *counts,
+                      int64_t *cluster_n, int64_t *max_id);
+
+/* ---- cluster plugin protocol on the device (unit-level parity) ----------
+ * A batch of B stand-alone clusters of dataset k.  cluster_add!: rows[b] (1-based
+ * row of dataFiles[k]) is added to cluster b; calc_logprob: log posterior
+ * predictive of row obs_rows[b] under cluster b; calc_logmarginal: D_k values
+ * per cluster.  Replaces, per type, gaussian_cluster.jl:37-83,
+ * categorical_cluster.jl:29-66, negbinom_cluster.jl:22-60. */
+typedef struct pmdi_cluster_batch pmdi_cluster_batch;
+int pmdi_clusters_new(pmdi_handle *h, int32_t k, int32_t B, pmdi_cluster_batch **out);
+int pmdi_clusters_free(pmdi_cluster_batch *cb);
+int pmdi_cluster_add(pmdi_cluster_batch *cb, const int64_t *rows, const uint8_t *feature_flag);
+int pmdi_calc_logprob(pmdi_cluster_batch *cb, const int64_t *obs_rows, const uint8_t *feature_flag,
+                      double *out);
+int pmdi_calc_logmarginal(pmdi_cluster_batch *cb, double *out /* B x D_k, row per cluster */);
+/* stats per cluster: Gaussian n, mu[D], Sigma[D], lambda[D], beta[D];
+ * Categorical n, counts[L x D col-major]; NegBinom n, Sigma[D]; returns the
+ * number of doubles per cluster in *stride */
+int pmdi_cluster_stats(pmdi_cluster_batch *cb, double *out, int64_t *stride);
+
+/* sizes a caller needs to allocate outputs */
+int pmdi_sum_D(const pmdi_handle *h);
+int64_t pmdi_pool_cap(const pmdi_handle *h);
+int pmdi_categorical_L(const pmdi_handle *h, int32_t k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

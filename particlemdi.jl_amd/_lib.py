@@ -1,0 +1,277 @@
+"""ctypes binding of libpmdi_hip.so (include/pmdi_hip.h) and its build recipe.
+
+There is no CPU fallback in this package: if the HIP library is missing or no
+gfx950 device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libpmdi_hip.so")
+_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_kernels.hip", "pmdi_api.cpp")]
+_HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_ROOT, "include", "pmdi_hip.h")]
+
+GAUSSIAN, CATEGORICAL, NEGBINOM = 0, 1, 2
+KIND_BY_NAME = {"gaussian": GAUSSIAN, "categorical": CATEGORICAL, "negbinom": NEGBINOM,
+                "GaussianCluster": GAUSSIAN, "CategoricalCluster": CATEGORICAL,
+                "NegBinomCluster": NEGBINOM}
+ABI_VERSION = 1
+KMAX = 8
+
+EXPORTS = [
+    "pmdi_create", "pmdi_destroy", "pmdi_last_error", "pmdi_abi_version", "pmdi_sweep",
+    "pmdi_sweep_device", "pmdi_feature_select", "pmdi_export_state", "pmdi_clusters_new",
+    "pmdi_clusters_free", "pmdi_cluster_add", "pmdi_calc_logprob", "pmdi_calc_logmarginal",
+    "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L",
+]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = _SOURCES + _HEADERS
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+           "-shared", "-o", LIB_PATH] + _SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class PmdiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class _Dataset(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("D", C.c_int32), ("ld", C.c_int64),
+                ("xf", C.POINTER(C.c_double)), ("xi", C.POINTER(C.c_int64))]
+
+
+class _Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("K", C.c_int32),
+                ("N", C.c_int32), ("P", C.c_int32), ("n_chains", C.c_int32), ("n", C.c_int64),
+                ("seed", C.c_uint64), ("q1_mode", C.c_int32), ("q2_mode", C.c_int32),
+                ("pool_cap", C.c_int64), ("block_threads", C.c_int32), ("reserved", C.c_int32)]
+
+
+class SweepStats(C.Structure):
+    _fields_ = [("n_operations", C.c_int64), ("n_resamples", C.c_int64), ("n_clones", C.c_int64),
+                ("max_id", C.c_int64), ("sum_classes", C.c_int64), ("reserved", C.c_int64 * 3)]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_[:5]}
+
+
+_lib = None
+
+
+def lib():
+    """Load libpmdi_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PmdiError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.pmdi_last_error.restype = C.c_char_p
+    L.pmdi_abi_version.restype = C.c_int
+    L.pmdi_create.restype = C.c_int
+    L.pmdi_create.argtypes = [C.POINTER(_Config), C.POINTER(_Dataset), C.POINTER(vp)]
+    L.pmdi_destroy.argtypes = [vp]
+    L.pmdi_sweep.restype = C.c_int
+    L.pmdi_sweep.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
+    L.pmdi_sweep_device.restype = C.c_int
+    L.pmdi_sweep_device.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, vp, vp, vp]
+    L.pmdi_feature_select.restype = C.c_int
+    L.pmdi_feature_select.argtypes = [vp, i64, vp, vp, vp]
+    L.pmdi_export_state.restype = C.c_int
+    L.pmdi_export_state.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.pmdi_clusters_new.restype = C.c_int
+    L.pmdi_clusters_new.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.pmdi_clusters_free.argtypes = [vp]
+    L.pmdi_cluster_add.restype = C.c_int
+    L.pmdi_cluster_add.argtypes = [vp, vp, vp]
+    L.pmdi_calc_logprob.restype = C.c_int
+    L.pmdi_calc_logprob.argtypes = [vp, vp, vp, vp]
+    L.pmdi_calc_logmarginal.restype = C.c_int
+    L.pmdi_calc_logmarginal.argtypes = [vp, vp]
+    L.pmdi_cluster_stats.restype = C.c_int
+    L.pmdi_cluster_stats.argtypes = [vp, vp, vp]
+    L.pmdi_sum_D.restype = C.c_int
+    L.pmdi_sum_D.argtypes = [vp]
+    L.pmdi_pool_cap.restype = i64
+    L.pmdi_pool_cap.argtypes = [vp]
+    L.pmdi_categorical_L.restype = C.c_int
+    L.pmdi_categorical_L.argtypes = [vp, i32]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise PmdiError(rc, lib().pmdi_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Sweeper:
+    """A batch of `n_chains` independent chains on one MI355X: the device side of
+    pmdi()'s per-iteration sweep (src/pmdi.jl:165-171, 188-350, 354-370)."""
+
+    def __init__(self, data, kinds, N, P, n_chains=1, seed=0, device=0, q1_mode=0, q2_mode=0,
+                 pool_cap=0, block_threads=0):
+        L = lib()
+        self.K = len(data)
+        if self.K > KMAX:
+            raise PmdiError(-1, f"K={self.K} > {KMAX}")
+        self.n = int(data[0].shape[0])
+        self.N, self.P, self.C = int(N), int(P), int(n_chains)
+        self.D = [int(x.shape[1]) for x in data]
+        self.kinds = [KIND_BY_NAME.get(k, k) for k in kinds]
+        if len(self.kinds) != self.K:
+            raise PmdiError(-1, "Number of datatypes not equal to number of datasets")
+        ds = (_Dataset * self.K)()
+        self._keep = []
+        for k, (x, kind) in enumerate(zip(data, self.kinds)):
+            if x.shape[0] != self.n:
+                raise PmdiError(-1, "Datasets don't have same number of observations.")
+            ds[k].kind, ds[k].D, ds[k].ld = kind, x.shape[1], self.n
+            if kind == GAUSSIAN:
+                xf = np.asfortranarray(x, dtype=np.float64)
+                self._keep.append(xf)
+                ds[k].xf = xf.ctypes.data_as(C.POINTER(C.c_double))
+            else:
+                xi = np.asfortranarray(x, dtype=np.int64)
+                self._keep.append(xi)
+                ds[k].xi = xi.ctypes.data_as(C.POINTER(C.c_int64))
+        cfg = _Config(ABI_VERSION, device, self.K, self.N, self.P, self.C, self.n, int(seed),
+                      q1_mode, q2_mode, int(pool_cap), int(block_threads), 0)
+        h = C.c_void_p()
+        _check(L.pmdi_create(C.byref(cfg), ds, C.byref(h)))
+        self.h = h
+        self.sumD = L.pmdi_sum_D(h)
+        self.cap = L.pmdi_pool_cap(h)
+        self.npairs = max(1, self.K * (self.K - 1) // 2)
+        self._keep = None  # the library copied the data
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pmdi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sweep(self, it, s, order_obs, n1, Pi, Phi, flags=None, lw_init=None, trace=False):
+        """Per chain (leading axis C, dropped when n_chains == 1 inputs are 2-D):
+        s (C, n, K) labels 1..N; order_obs (C, n) 1-based; Pi (C, N, K); Phi (C, npairs);
+        flags (C, sumD) bytes or None."""
+        C_, K, n, N, P = self.C, self.K, self.n, self.N, self.P
+        s_a = np.asarray(s, dtype=np.int64).reshape(C_, n, K)
+        s_in = np.ascontiguousarray(np.transpose(s_a, (0, 2, 1)))          # column-major n x K per chain
+        order = np.ascontiguousarray(np.asarray(order_obs, dtype=np.int64).reshape(C_, n))
+        Pi_a = np.asarray(Pi, dtype=np.float64).reshape(C_, N, K)
+        Pi_in = np.ascontiguousarray(np.transpose(Pi_a, (0, 2, 1)))
+        Phi_in = np.ascontiguousarray(np.asarray(Phi, dtype=np.float64).reshape(C_, self.npairs))
+        fl = None
+        if flags is not None:
+            fl = np.ascontiguousarray(np.asarray(flags, dtype=np.uint8).reshape(C_, self.sumD))
+        if lw_init is None:
+            lw_init = 0.0 if it == 1 else 1.0
+        s_out = np.zeros((C_, K, n), dtype=np.int64)
+        lw = np.zeros((C_, P), dtype=np.float64)
+        p_star = np.zeros(C_, dtype=np.int64)
+        st = (SweepStats * C_)()
+        tr = np.zeros((C_, n - n1 + 1, 2 + 2 * K), dtype=np.float64) if trace else None
+        _check(lib().pmdi_sweep(self.h, int(it), _ptr(s_in), _ptr(order), int(n1), _ptr(Pi_in),
+                                _ptr(Phi_in), _ptr(fl), float(lw_init), _ptr(s_out), _ptr(lw),
+                                _ptr(p_star), C.cast(st, C.c_void_p), _ptr(tr)))
+        out = {"s": np.transpose(s_out, (0, 2, 1)).copy(), "logweight": lw, "p_star": p_star,
+               "stats": [st[c].as_dict() for c in range(C_)]}
+        if trace:
+            out["trace"] = tr
+        return out
+
+    def feature_select(self, it, s_traj):
+        C_, K, n = self.C, self.K, self.n
+        s_a = np.asarray(s_traj, dtype=np.int64).reshape(C_, n, K)
+        s_in = np.ascontiguousarray(np.transpose(s_a, (0, 2, 1)))
+        flags = np.zeros((C_, self.sumD), dtype=np.uint8)
+        prob = np.zeros((C_, self.sumD), dtype=np.float64)
+        _check(lib().pmdi_feature_select(self.h, int(it), _ptr(s_in), _ptr(flags), _ptr(prob)))
+        return flags, prob
+
+    def export_state(self, chain=0):
+        K, N, P, cap = self.K, self.N, self.P, self.cap
+        particle = np.zeros((K, P, N), dtype=np.int64)
+        counts = np.zeros((K, cap), dtype=np.int64)
+        cn = np.zeros((K, cap), dtype=np.int64)
+        mx = np.zeros(K, dtype=np.int64)
+        _check(lib().pmdi_export_state(self.h, int(chain), _ptr(particle), _ptr(counts), _ptr(cn), _ptr(mx)))
+        return {"particle": particle, "counts": counts, "cluster_n": cn, "max_id": mx}
+
+    def clusters(self, k, B):
+        return ClusterBatch(self, k, B)
+
+
+class ClusterBatch:
+    """B stand-alone clusters of dataset k on the device: the calc_logprob /
+    cluster_add! / calc_logmarginal protocol of src/datatypes/*.jl."""
+
+    def __init__(self, sweeper, k, B):
+        self.sw, self.k, self.B = sweeper, int(k), int(B)
+        self.D = sweeper.D[k]
+        self.kind = sweeper.kinds[k]
+        h = C.c_void_p()
+        _check(lib().pmdi_clusters_new(sweeper.h, self.k, self.B, C.byref(h)))
+        self.h = h
+
+    def add(self, rows, flag=None):
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(rows, dtype=np.int64), (self.B,)))
+        f = None if flag is None else np.ascontiguousarray(flag, dtype=np.uint8)
+        _check(lib().pmdi_cluster_add(self.h, _ptr(r), _ptr(f)))
+
+    def logprob(self, rows, flag=None):
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(rows, dtype=np.int64), (self.B,)))
+        f = None if flag is None else np.ascontiguousarray(flag, dtype=np.uint8)
+        out = np.zeros(self.B)
+        _check(lib().pmdi_calc_logprob(self.h, _ptr(r), _ptr(f), _ptr(out)))
+        return out
+
+    def logmarginal(self):
+        out = np.zeros((self.B, self.D))
+        _check(lib().pmdi_calc_logmarginal(self.h, _ptr(out)))
+        return out
+
+    def stats(self):
+        stride = C.c_int64(0)
+        _check(lib().pmdi_cluster_stats(self.h, None, C.addressof(stride)))
+        out = np.zeros((self.B, stride.value))
+        _check(lib().pmdi_cluster_stats(self.h, _ptr(out), C.addressof(stride)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pmdi_clusters_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,656 @@
+// pmdi_api.cpp -- host side of the C ABI declared in include/pmdi_hip.h.
+// Converts the reference's conventions (column-major, 1-based Int64) at the
+// boundary, owns device memory, builds the exact-arithmetic lookup tables and
+// launches the kernels of pmdi_kernels.hip.  No CPU fallback exists: every
+// compute entry point runs on the gfx950 device or fails.
+#include "pmdi_internal.h"
+#include "../../include/pmdi_hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess)                                                         \
+            return fail(e__ == hipErrorOutOfMemory ? PMDI_E_MEMORY : PMDI_E_DEVICE,    \
+                        "%s: %s", #expr, hipGetErrorString(e__));                      \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t b)
+    {
+        if (b <= bytes && p) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (b == 0) b = 16;
+        hipError_t e = hipMalloc(&p, b);
+        if (e != hipSuccess) { p = nullptr; return fail(PMDI_E_MEMORY, "hipMalloc(%zu): %s", b, hipGetErrorString(e)); }
+        bytes = b;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// fills the arena offsets of one dataset; returns the per-chain stride
+size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_sstar, bool sweep_state)
+{
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t ids = (size_t)cap + 1;
+    if (sweep_state) {
+        d.o_particle[0] = take((size_t)N * P * 4);
+        d.o_particle[1] = take((size_t)N * P * 4);
+        d.o_pid = take((size_t)P * 4);
+        d.o_sid = take((size_t)P * 4);
+        d.o_newid = take((size_t)N * P * 4);
+        d.o_counts = take(ids * 4);
+        d.o_ncop = take(ids * 4);
+        d.o_firstc = take(ids * 4);
+        d.o_lp = take(ids * 8);
+        d.o_sstar = take((size_t)n_rows_sstar * P);
+        d.o_clslead = take((size_t)P * 4);
+        d.o_clsval = take((size_t)P * 4);
+        d.o_cdf = take((size_t)P * (N + 1) * 8);
+        d.o_dl = take((size_t)3 * P * 4);
+    }
+    d.o_cn = take(ids * 4);
+    if (d.kind == K_GAUSSIAN) {
+        d.o_ml = take(ids * d.D * 16);
+        d.o_sb = take(ids * d.D * 16);
+    } else if (d.kind == K_CATEGORICAL) {
+        d.o_cnt = take(ids * d.D * d.L * 4);
+    } else {
+        d.o_nbs = take(ids * d.D * 8);
+    }
+    return o;
+}
+
+}  // namespace
+
+struct pmdi_handle {
+    pmdi_config cfg{};
+    int T = 0;
+    long long cap = 0;
+    int Dmax = 0, sumD = 0, npairs = 1;
+    int terms_cap = 0;
+    hipStream_t stream = nullptr;
+    DsetDev ds[PMDI_KMAX_I]{};
+    std::vector<void *> owned;          // device allocations freed in destroy
+    // per-call staging (device)
+    DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
+    DevBuf d_usc, d_partstar, d_kstate;
+    // feature selection
+    DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
+    bool swept = false;
+    long long last_n1 = 0;
+};
+
+struct pmdi_cluster_batch {
+    pmdi_handle *h = nullptr;
+    int k = 0, B = 0;
+    DsetDev d{};
+    void *arena = nullptr;
+    DevBuf d_rows, d_flags, d_out;
+};
+
+namespace {
+
+int dev_alloc(pmdi_handle *h, void **p, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { *p = nullptr; return fail(PMDI_E_MEMORY, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    h->owned.push_back(*p);
+    return 0;
+}
+
+template <class Tt>
+int upload(pmdi_handle *h, const std::vector<Tt> &v, const Tt **out)
+{
+    void *p = nullptr;
+    int rc = dev_alloc(h, &p, v.size() * sizeof(Tt));
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(Tt), hipMemcpyHostToDevice));
+    *out = (const Tt *)p;
+    return 0;
+}
+
+void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
+{
+    memset(&a, 0, sizeof(a));
+    a.K = h->cfg.K; a.N = h->cfg.N; a.P = h->cfg.P; a.cap = (int)h->cap;
+    a.Dmax = h->Dmax; a.sumD = h->sumD; a.npairs = h->npairs;
+    a.q1 = h->cfg.q1_mode; a.q2 = h->cfg.q2_mode;
+    a.terms_cap = h->terms_cap;
+    a.n = h->cfg.n;
+    a.seed = h->cfg.seed;
+    for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pmdi_last_error(void) { return g_err; }
+int pmdi_abi_version(void) { return PMDI_ABI_VERSION; }
+
+int pmdi_destroy(pmdi_handle *h)
+{
+    if (!h) return PMDI_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->owned) (void)hipFree(p);
+    DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate,
+                      &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
+    for (DevBuf *b : bufs) b->release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PMDI_OK;
+}
+
+int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handle **out)
+{
+    if (!cfg || !datasets || !out) return fail(PMDI_E_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != PMDI_ABI_VERSION) return fail(PMDI_E_ARG, "abi_version %d != %d", cfg->abi_version, PMDI_ABI_VERSION);
+    const int K = cfg->K, N = cfg->N, P = cfg->P;
+    const long long n = cfg->n;
+    // the @asserts of src/pmdi.jl:50-55 that concern this path
+    if (K < 1 || K > PMDI_KMAX_I) return fail(PMDI_E_ARG, "K=%d outside 1..%d", K, PMDI_KMAX_I);
+    if (n < 2 || n > 0x7fffffffLL / 4) return fail(PMDI_E_ARG, "n=%lld out of range", n);
+    if (!(N <= n && N > 1)) return fail(PMDI_E_ARG, "Number of clusters must be greater than 1 and not greater than the number of observations");
+    if (N > 64) return fail(PMDI_E_ARG, "N=%d: this build supports N <= 64", N);
+    if (P < 2) return fail(PMDI_E_ARG, "Conditional particle filter requires 2 or more particles");
+    if (P > 1048575) return fail(PMDI_E_ARG, "P=%d too large", P);
+    if (cfg->n_chains < 1) return fail(PMDI_E_ARG, "n_chains must be >= 1");
+    if (cfg->q1_mode < 0 || cfg->q1_mode > 1) return fail(PMDI_E_ARG, "q1_mode must be 0 or 1");
+    if (cfg->q2_mode != 0) return fail(PMDI_E_ARG, "q2_mode=1 (__pmdi history permutation) is not implemented yet");
+    long long cap = cfg->pool_cap > 0 ? cfg->pool_cap : (long long)N * P + 1;
+    if (cap > (long long)N * P + 1) cap = (long long)N * P + 1;
+    if (cap < N + 2) return fail(PMDI_E_ARG, "pool_cap too small");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(PMDI_E_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(PMDI_E_DEVICE, "device %d not in 0..%d", cfg->device, ndev - 1);
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PMDI_E_DEVICE, "device %d is %s; the kernels are built for gfx950 only", cfg->device, prop.gcnArchName);
+
+    pmdi_handle *h = new (std::nothrow) pmdi_handle();
+    if (!h) return fail(PMDI_E_MEMORY, "out of host memory");
+    h->cfg = *cfg;
+    h->cap = cap;
+    h->npairs = K > 1 ? K * (K - 1) / 2 : 1;
+    int rc = 0;
+    auto bail = [&](int code) { pmdi_destroy(h); return code; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipStreamCreate failed"));
+
+    int flag_off = 0;
+    for (int k = 0; k < K; ++k) {
+        const pmdi_dataset &src = datasets[k];
+        DsetDev &d = h->ds[k];
+        if (src.D < 1) return bail(fail(PMDI_E_ARG, "dataset %d: D=%d", k, src.D));
+        if (src.ld < n) return bail(fail(PMDI_E_ARG, "dataset %d: ld=%lld < n. Datasets don't have same number of observations.", k, (long long)src.ld));
+        d.kind = src.kind; d.D = src.D; d.L = 0; d.flag_off = flag_off;
+        flag_off += src.D;
+        if (src.D > h->Dmax) h->Dmax = src.D;
+        const int D = src.D;
+        if (src.kind == PMDI_GAUSSIAN) {
+            if (!src.xf) return bail(fail(PMDI_E_ARG, "dataset %d: xf is null", k));
+            std::vector<double> x((size_t)n * D);
+            for (long long i = 0; i < n; ++i)
+                for (int q = 0; q < D; ++q) x[(size_t)i * D + q] = src.xf[(size_t)q * src.ld + i];
+            if ((rc = upload(h, x, &d.xf))) return bail(rc);
+            // gaussian_cluster.jl:38-40 prefix and :76-79 constant, per cluster size
+            std::vector<double> g((size_t)n + 1), lm((size_t)n + 1);
+            for (long long m = 0; m <= n; ++m) {
+                const double nn = (double)m;
+                g[m] = (log(1.0 / sqrt(M_PI)) + lgamma(0.5 * nn + 1.0)) - lgamma(0.5 * nn + 0.5);
+                const double a_n = (nn / 2.0 + 0.5), a_0 = 0.5, b_0 = 0.5, k_0 = 0.001, k_n = nn + k_0;
+                lm[m] = (a_0 * log(b_0)) + lgamma(a_n) - lgamma(a_0) + 0.5 * (log(k_0) - log(k_n)) -
+                        (nn * 0.5) * log(2.0 * M_PI);
+            }
+            if ((rc = upload(h, g, &d.gtab))) return bail(rc);
+            if ((rc = upload(h, lm, &d.lmtab))) return bail(rc);
+        } else if (src.kind == PMDI_CATEGORICAL || src.kind == PMDI_NEGBINOM) {
+            if (!src.xi) return bail(fail(PMDI_E_ARG, "dataset %d: xi is null", k));
+            std::vector<int> x((size_t)n * D);
+            std::vector<int> maxcol(D, 0);
+            std::vector<long long> colsum(D, 0);
+            long long gmax = 0;
+            for (long long i = 0; i < n; ++i)
+                for (int q = 0; q < D; ++q) {
+                    const long long v = src.xi[(size_t)q * src.ld + i];
+                    if (src.kind == PMDI_CATEGORICAL && v < 1) return bail(fail(PMDI_E_DATA, "dataset %d: categorical level %lld < 1", k, v));
+                    if (src.kind == PMDI_NEGBINOM && v < 0) return bail(fail(PMDI_E_DATA, "dataset %d: negative count %lld", k, v));
+                    if (v > 0x3fffffff) return bail(fail(PMDI_E_DATA, "dataset %d: value %lld too large", k, v));
+                    x[(size_t)i * D + q] = (int)v;
+                    if (v > maxcol[q]) maxcol[q] = (int)v;
+                    if (v > gmax) gmax = v;
+                    colsum[q] += v;
+                }
+            if ((rc = upload(h, x, &d.xi))) return bail(rc);
+            if (src.kind == PMDI_CATEGORICAL) {
+                if (gmax > 4096) return bail(fail(PMDI_E_DATA, "dataset %d: %lld categorical levels (max 4096)", k, gmax));
+                d.L = (int)gmax;                                  // categorical_cluster.jl:8
+                if ((rc = upload(h, maxcol, &d.maxcol))) return bail(rc);
+                std::vector<double> lh((size_t)(2 * n + gmax + 3)), lgh((size_t)(2 * (n + gmax) + 3));
+                for (size_t j = 0; j < lh.size(); ++j) lh[j] = log(0.5 * (double)j);
+                for (size_t j = 0; j < lgh.size(); ++j) lgh[j] = lgamma(0.5 * (double)j);
+                if ((rc = upload(h, lh, &d.lhtab))) return bail(rc);
+                if ((rc = upload(h, lgh, &d.lghtab))) return bail(rc);
+            } else {
+                long long smax = 0;
+                for (int q = 0; q < D; ++q) if (colsum[q] > smax) smax = colsum[q];
+                const long long len = n + gmax + smax + 8;
+                if (len > (1LL << 27)) return bail(fail(PMDI_E_DATA, "dataset %d: NegBinom lgamma table of %lld entries is too large", k, len));
+                std::vector<double> lg((size_t)len);
+                for (long long m = 0; m < len; ++m) lg[m] = lgamma((double)m);
+                if ((rc = upload(h, lg, &d.lgtab))) return bail(rc);
+                d.lgtab_len = len;
+            }
+        } else {
+            return bail(fail(PMDI_E_ARG, "dataset %d: unknown kind %d", k, src.kind));
+        }
+        d.stride = layout_arena(d, N, P, cap, n, true);
+        void *arena = nullptr;
+        if ((rc = dev_alloc(h, &arena, d.stride * (size_t)cfg->n_chains))) return bail(rc);
+        d.arena = (char *)arena;
+        if (hipMemset(arena, 0, d.stride * (size_t)cfg->n_chains) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));
+    }
+    h->sumD = flag_off;
+    h->T = cfg->block_threads ? cfg->block_threads : (P >= 1024 ? 1024 : (P > 256 ? 512 : 256));
+    if (h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 256, 512 or 1024"));
+    {
+        // LDS term buffer: at least P doubles (resampling weights) and a few rows of 2*D+1
+        int tc = 4096;
+        if (tc < P) tc = P;
+        if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
+        h->terms_cap = tc;
+        SweepArgs a;
+        fill_sweep_common(h, a);
+        if (pmdi_sweep_lds_bytes(a, h->T) > 160 * 1024)
+            return bail(fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, h->T)));
+    }
+    const int C = cfg->n_chains;
+    if ((rc = h->d_usc.ensure((size_t)C * P * 8)) || (rc = h->d_partstar.ensure((size_t)C * P * 4)) ||
+        (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
+        (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)))
+        return bail(rc);
+
+    // null-cluster marginal (src/pmdi.jl:120-128): all rows in one cluster, all features on
+    {
+        std::vector<int> traj((size_t)K * n, 0);
+        if ((rc = h->d_traj.ensure((size_t)C * K * n * 4)) || (rc = h->d_lm.ensure((size_t)C * h->sumD * N * 8)) ||
+            (rc = h->d_firstpos.ensure((size_t)C * K * N * 4)) || (rc = h->d_fnull.ensure((size_t)h->sumD * 8)) ||
+            (rc = h->d_fflags.ensure((size_t)C * h->sumD)) || (rc = h->d_fprob.ensure((size_t)C * h->sumD * 8)))
+            return bail(rc);
+        if (hipMemcpy(h->d_traj.p, traj.data(), traj.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "memcpy failed"));
+        std::vector<double> zero((size_t)h->sumD, 0.0);
+        if (hipMemcpy(h->d_fnull.p, zero.data(), zero.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "memcpy failed"));
+        FeatSelArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.K = K; fa.N = 1; fa.sumD = h->sumD; fa.n = n; fa.iter = 0; fa.seed = cfg->seed;
+        for (int k = 0; k < K; ++k) fa.ds[k] = h->ds[k];
+        fa.traj = (const int *)h->d_traj.p; fa.lm = (double *)h->d_lm.p; fa.firstpos = (int *)h->d_firstpos.p;
+        fa.fnull = (const double *)h->d_fnull.p; fa.flags_out = (unsigned char *)h->d_fflags.p; fa.prob_out = (double *)h->d_fprob.p;
+        hipError_t e = pmdi_launch_featsel(fa, 1, h->stream);
+        if (e != hipSuccess) return bail(fail(PMDI_E_DEVICE, "null-marginal launch: %s", hipGetErrorString(e)));
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "null-marginal kernel failed"));
+        std::vector<double> lm((size_t)h->sumD);
+        if (hipMemcpy(lm.data(), h->d_lm.p, lm.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "memcpy failed"));
+        for (double &v : lm) v = -v;                               // featureNull = -calc_logmarginal (:127)
+        if (hipMemcpy(h->d_fnull.p, lm.data(), lm.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "memcpy failed"));
+    }
+    *out = h;
+    return PMDI_OK;
+}
+
+int pmdi_sum_D(const pmdi_handle *h) { return h ? h->sumD : 0; }
+int64_t pmdi_pool_cap(const pmdi_handle *h) { return h ? h->cap : 0; }
+int pmdi_categorical_L(const pmdi_handle *h, int32_t k) { return (h && k >= 0 && k < h->cfg.K) ? h->ds[k].L : 0; }
+
+int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const int32_t *order_obs, int64_t n1,
+                      const double *Pi, const double *log1p_phi, const uint8_t *feature_flag, double lw_init,
+                      int32_t *s_out, double *logweight, int32_t *p_star, int64_t *stats, int32_t *err, void *stream)
+{
+    if (!h || !s_in || !order_obs || !Pi || !log1p_phi || !s_out) return fail(PMDI_E_ARG, "null argument");
+    if (n1 < 1 || n1 > h->cfg.n) return fail(PMDI_E_ARG, "n1=%lld outside 1..n (rho*n < 1 is undefined in the reference)", (long long)n1);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    SweepArgs a;
+    fill_sweep_common(h, a);
+    a.iter = (unsigned)iter; a.n1 = n1; a.lw_init = lw_init;
+    a.s_in = s_in; a.order = order_obs; a.Pi = Pi; a.logphi = log1p_phi; a.flags = feature_flag;
+    a.s_out = s_out; a.lw_out = logweight;
+    a.pstar = p_star ? p_star : (int *)h->d_pstar.p;
+    a.stats = stats ? (long long *)stats : (long long *)h->d_stats.p;
+    a.err = err ? err : (int *)h->d_err.p;
+    a.trace = nullptr; a.trace_on = 0;
+    a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipError_t e = pmdi_launch_sweep(a, h->cfg.n_chains, h->T, st);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
+    h->swept = true; h->last_n1 = n1;
+    return PMDI_OK;
+}
+
+int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t *order_obs, int64_t n1,
+               const double *Pi, const double *Phi, const uint8_t *feature_flag, double lw_init, int64_t *s_out,
+               double *logweight, int64_t *p_star, pmdi_sweep_stats *stats, double *trace)
+{
+    if (!h || !s_in || !order_obs || !Pi || !Phi) return fail(PMDI_E_ARG, "null argument");
+    const int K = h->cfg.K, N = h->cfg.N, P = h->cfg.P, C = h->cfg.n_chains;
+    const long long n = h->cfg.n;
+    if (n1 < 1 || n1 > n) return fail(PMDI_E_ARG, "n1=%lld outside 1..n (rho*n < 1 is undefined in the reference)", (long long)n1);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<int> s32((size_t)C * K * n), o32((size_t)C * n);
+    for (size_t i = 0; i < s32.size(); ++i) {
+        const long long v = s_in[i];
+        if (v < 1 || v > N) return fail(PMDI_E_DATA, "s_in[%zu]=%lld outside 1..N", i, v);
+        s32[i] = (int)(v - 1);
+    }
+    for (size_t i = 0; i < o32.size(); ++i) {
+        const long long v = order_obs[i];
+        if (v < 1 || v > n) return fail(PMDI_E_DATA, "order_obs[%zu]=%lld outside 1..n", i, v);
+        o32[i] = (int)(v - 1);
+    }
+    std::vector<double> lphi((size_t)C * h->npairs);
+    for (size_t i = 0; i < lphi.size(); ++i) lphi[i] = log(1.0 + Phi[i]);   // src/misc.jl:53
+    int rc;
+    const long long ns = n - n1 + 1;
+    if ((rc = h->d_s_in.ensure(s32.size() * 4)) || (rc = h->d_order.ensure(o32.size() * 4)) ||
+        (rc = h->d_Pi.ensure((size_t)C * K * N * 8)) || (rc = h->d_logphi.ensure(lphi.size() * 8)) ||
+        (rc = h->d_s_out.ensure(s32.size() * 4)) || (rc = h->d_lw.ensure((size_t)C * P * 8)))
+        return rc;
+    if (feature_flag && (rc = h->d_flags.ensure((size_t)C * h->sumD))) return rc;
+    if (trace && (rc = h->d_trace.ensure((size_t)C * ns * (2 + 2 * K) * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(h->d_s_in.p, s32.data(), s32.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_order.p, o32.data(), o32.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_Pi.p, Pi, (size_t)C * K * N * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->d_logphi.p, lphi.data(), lphi.size() * 8, hipMemcpyHostToDevice, h->stream));
+    if (feature_flag) HIP_TRY(hipMemcpyAsync(h->d_flags.p, feature_flag, (size_t)C * h->sumD, hipMemcpyHostToDevice, h->stream));
+
+    SweepArgs a;
+    fill_sweep_common(h, a);
+    a.iter = (unsigned)iter; a.n1 = n1; a.lw_init = lw_init;
+    a.s_in = (const int *)h->d_s_in.p; a.order = (const int *)h->d_order.p; a.Pi = (const double *)h->d_Pi.p;
+    a.logphi = (const double *)h->d_logphi.p; a.flags = feature_flag ? (const unsigned char *)h->d_flags.p : nullptr;
+    a.s_out = (int *)h->d_s_out.p; a.lw_out = (double *)h->d_lw.p; a.pstar = (int *)h->d_pstar.p;
+    a.stats = (long long *)h->d_stats.p; a.err = (int *)h->d_err.p;
+    a.trace = trace ? (double *)h->d_trace.p : nullptr; a.trace_on = trace ? 1 : 0;
+    a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
+    hipError_t e = pmdi_launch_sweep(a, C, h->T, h->stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
+    std::vector<int> so(s32.size()), ps(C), er(C);
+    std::vector<long long> stv((size_t)C * 8);
+    HIP_TRY(hipMemcpyAsync(so.data(), h->d_s_out.p, so.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(ps.data(), h->d_pstar.p, (size_t)C * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(er.data(), h->d_err.p, (size_t)C * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(stv.data(), h->d_stats.p, stv.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    if (logweight) HIP_TRY(hipMemcpyAsync(logweight, h->d_lw.p, (size_t)C * P * 8, hipMemcpyDeviceToHost, h->stream));
+    if (trace) HIP_TRY(hipMemcpyAsync(trace, h->d_trace.p, (size_t)C * ns * (2 + 2 * K) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->swept = true; h->last_n1 = n1;
+    for (int c = 0; c < C; ++c)
+        if (er[c] != 0)
+            return fail(er[c] == PMDI_E_POOL ? PMDI_E_POOL : PMDI_E_STATE,
+                        er[c] == PMDI_E_POOL ? "chain %d: cluster pool capacity %lld exceeded" : "chain %d: kernel reported error", c, h->cap);
+    if (s_out) for (size_t i = 0; i < so.size(); ++i) s_out[i] = (int64_t)so[i] + 1;
+    if (p_star) for (int c = 0; c < C; ++c) p_star[c] = (int64_t)ps[c] + 1;
+    if (stats)
+        for (int c = 0; c < C; ++c) {
+            memset(&stats[c], 0, sizeof(pmdi_sweep_stats));
+            stats[c].n_operations = stv[(size_t)c * 8 + ST_NOPS];
+            stats[c].n_resamples = stv[(size_t)c * 8 + ST_NRESAMPLE];
+            stats[c].n_clones = stv[(size_t)c * 8 + ST_NCLONES];
+            stats[c].max_id = stv[(size_t)c * 8 + ST_MAXID];
+            stats[c].sum_classes = stv[(size_t)c * 8 + ST_SUMCLASSES];
+        }
+    return PMDI_OK;
+}
+
+int pmdi_export_state(pmdi_handle *h, int32_t chain, int64_t *particle, int64_t *counts, int64_t *cluster_n,
+                      int64_t *max_id)
+{
+    if (!h) return fail(PMDI_E_ARG, "null handle");
+    if (!h->swept) return fail(PMDI_E_STATE, "no sweep has run on this handle");
+    if (chain < 0 || chain >= h->cfg.n_chains) return fail(PMDI_E_ARG, "chain out of range");
+    const int K = h->cfg.K, N = h->cfg.N, P = h->cfg.P;
+    const long long cap = h->cap;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<int> ks((size_t)PMDI_KMAX_I * 2);
+    HIP_TRY(hipMemcpy(ks.data(), (char *)h->d_kstate.p + (size_t)chain * PMDI_KMAX_I * 2 * 4, ks.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<int> tmp((size_t)N * P), tc((size_t)cap + 1);
+    for (int k = 0; k < K; ++k) {
+        const DsetDev &d = h->ds[k];
+        const char *base = d.arena + (size_t)chain * d.stride;
+        const int cur = ks[(size_t)k * 2 + 1];
+        if (particle) {
+            HIP_TRY(hipMemcpy(tmp.data(), base + d.o_particle[cur], tmp.size() * 4, hipMemcpyDeviceToHost));
+            for (int p = 0; p < P; ++p)                               // particle[n, p, k], column-major
+                for (int nn = 0; nn < N; ++nn) particle[((size_t)k * P + p) * N + nn] = tmp[(size_t)nn * P + p];
+        }
+        if (counts) {
+            HIP_TRY(hipMemcpy(tc.data(), base + d.o_counts, tc.size() * 4, hipMemcpyDeviceToHost));
+            for (long long id = 1; id <= cap; ++id) counts[(size_t)k * cap + (id - 1)] = tc[id];
+        }
+        if (cluster_n) {
+            HIP_TRY(hipMemcpy(tc.data(), base + d.o_cn, tc.size() * 4, hipMemcpyDeviceToHost));
+            for (long long id = 1; id <= cap; ++id) cluster_n[(size_t)k * cap + (id - 1)] = tc[id];
+        }
+        if (max_id) max_id[k] = ks[(size_t)k * 2];
+    }
+    return PMDI_OK;
+}
+
+int pmdi_feature_select(pmdi_handle *h, int64_t iter, const int64_t *s_traj, uint8_t *feature_flag, double *feature_prob)
+{
+    if (!h || !s_traj) return fail(PMDI_E_ARG, "null argument");
+    const int K = h->cfg.K, N = h->cfg.N, C = h->cfg.n_chains;
+    const long long n = h->cfg.n;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<int> t32((size_t)C * K * n);
+    for (size_t i = 0; i < t32.size(); ++i) {
+        const long long v = s_traj[i];
+        if (v < 1 || v > N) return fail(PMDI_E_DATA, "s_traj[%zu]=%lld outside 1..N", i, v);
+        t32[i] = (int)(v - 1);
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_traj.p, t32.data(), t32.size() * 4, hipMemcpyHostToDevice, h->stream));
+    FeatSelArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.K = K; fa.N = N; fa.sumD = h->sumD; fa.n = n; fa.iter = (unsigned)iter; fa.seed = h->cfg.seed;
+    for (int k = 0; k < K; ++k) fa.ds[k] = h->ds[k];
+    fa.traj = (const int *)h->d_traj.p; fa.lm = (double *)h->d_lm.p; fa.firstpos = (int *)h->d_firstpos.p;
+    fa.fnull = (const double *)h->d_fnull.p; fa.flags_out = (unsigned char *)h->d_fflags.p; fa.prob_out = (double *)h->d_fprob.p;
+    hipError_t e = pmdi_launch_featsel(fa, C, h->stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "feature-select launch: %s", hipGetErrorString(e));
+    if (feature_flag) HIP_TRY(hipMemcpyAsync(feature_flag, h->d_fflags.p, (size_t)C * h->sumD, hipMemcpyDeviceToHost, h->stream));
+    if (feature_prob) HIP_TRY(hipMemcpyAsync(feature_prob, h->d_fprob.p, (size_t)C * h->sumD * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PMDI_OK;
+}
+
+// ---- stand-alone cluster batches ------------------------------------------
+int pmdi_clusters_new(pmdi_handle *h, int32_t k, int32_t B, pmdi_cluster_batch **out)
+{
+    if (!h || !out) return fail(PMDI_E_ARG, "null argument");
+    *out = nullptr;
+    if (k < 0 || k >= h->cfg.K || B < 1) return fail(PMDI_E_ARG, "bad dataset index or batch size");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    pmdi_cluster_batch *cb = new (std::nothrow) pmdi_cluster_batch();
+    if (!cb) return fail(PMDI_E_MEMORY, "out of host memory");
+    cb->h = h; cb->k = k; cb->B = B;
+    cb->d = h->ds[k];
+    cb->d.stride = layout_arena(cb->d, h->cfg.N, h->cfg.P, B, 0, false);
+    hipError_t e = hipMalloc(&cb->arena, cb->d.stride);
+    if (e != hipSuccess) { delete cb; return fail(PMDI_E_MEMORY, "hipMalloc: %s", hipGetErrorString(e)); }
+    cb->d.arena = (char *)cb->arena;
+    (void)hipMemset(cb->arena, 0, cb->d.stride);
+    if (cb->d.kind == K_GAUSSIAN) {     // GaussianCluster(dataFile): mu=Sigma=0, lambda=1, beta=0.5 (gaussian_cluster.jl:17-21)
+        std::vector<double> ml((size_t)(B + 1) * cb->d.D * 2), sb(ml.size());
+        for (size_t i = 0; i < ml.size(); i += 2) { ml[i] = 0.0; ml[i + 1] = 1.0; sb[i] = 0.0; sb[i + 1] = 0.5; }
+        (void)hipMemcpy(cb->d.arena + cb->d.o_ml, ml.data(), ml.size() * 8, hipMemcpyHostToDevice);
+        (void)hipMemcpy(cb->d.arena + cb->d.o_sb, sb.data(), sb.size() * 8, hipMemcpyHostToDevice);
+    }
+    *out = cb;
+    return PMDI_OK;
+}
+
+int pmdi_clusters_free(pmdi_cluster_batch *cb)
+{
+    if (!cb) return PMDI_OK;
+    (void)hipSetDevice(cb->h->cfg.device);
+    if (cb->arena) (void)hipFree(cb->arena);
+    cb->d_rows.release(); cb->d_flags.release(); cb->d_out.release();
+    delete cb;
+    return PMDI_OK;
+}
+
+static int batch_args(pmdi_cluster_batch *cb, const int64_t *rows, const uint8_t *flag, ClusterBatchArgs &a)
+{
+    const long long n = cb->h->cfg.n;
+    int rc;
+    memset(&a, 0, sizeof(a));
+    a.ds = cb->d; a.B = cb->B;
+    if (rows) {
+        std::vector<int> r32(cb->B);
+        for (int b = 0; b < cb->B; ++b) {
+            if (rows[b] < 1 || rows[b] > n) return fail(PMDI_E_ARG, "row %lld outside 1..n", (long long)rows[b]);
+            r32[b] = (int)(rows[b] - 1);
+        }
+        if ((rc = cb->d_rows.ensure((size_t)cb->B * 4))) return rc;
+        HIP_TRY(hipMemcpy(cb->d_rows.p, r32.data(), (size_t)cb->B * 4, hipMemcpyHostToDevice));
+        a.rows = (const int *)cb->d_rows.p;
+    }
+    if (flag) {
+        if ((rc = cb->d_flags.ensure((size_t)cb->d.D))) return rc;
+        HIP_TRY(hipMemcpy(cb->d_flags.p, flag, (size_t)cb->d.D, hipMemcpyHostToDevice));
+        a.flags = (const unsigned char *)cb->d_flags.p;
+    }
+    return 0;
+}
+
+int pmdi_cluster_add(pmdi_cluster_batch *cb, const int64_t *rows, const uint8_t *feature_flag)
+{
+    if (!cb || !rows) return fail(PMDI_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(cb->h->cfg.device));
+    ClusterBatchArgs a;
+    int rc = batch_args(cb, rows, feature_flag, a);
+    if (rc) return rc;
+    hipError_t e = pmdi_launch_cluster_add(a, cb->h->stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "cluster_add launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipStreamSynchronize(cb->h->stream));
+    return PMDI_OK;
+}
+
+int pmdi_calc_logprob(pmdi_cluster_batch *cb, const int64_t *obs_rows, const uint8_t *feature_flag, double *out)
+{
+    if (!cb || !obs_rows || !out) return fail(PMDI_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(cb->h->cfg.device));
+    ClusterBatchArgs a;
+    int rc = batch_args(cb, obs_rows, feature_flag, a);
+    if (rc) return rc;
+    if ((rc = cb->d_out.ensure((size_t)cb->B * 8))) return rc;
+    a.out = (double *)cb->d_out.p;
+    hipError_t e = pmdi_launch_cluster_logprob(a, cb->h->stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "calc_logprob launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(out, cb->d_out.p, (size_t)cb->B * 8, hipMemcpyDeviceToHost, cb->h->stream));
+    HIP_TRY(hipStreamSynchronize(cb->h->stream));
+    return PMDI_OK;
+}
+
+int pmdi_calc_logmarginal(pmdi_cluster_batch *cb, double *out)
+{
+    if (!cb || !out) return fail(PMDI_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(cb->h->cfg.device));
+    ClusterBatchArgs a;
+    int rc = batch_args(cb, nullptr, nullptr, a);
+    if (rc) return rc;
+    const size_t bytes = (size_t)cb->B * cb->d.D * 8;
+    if ((rc = cb->d_out.ensure(bytes))) return rc;
+    a.out = (double *)cb->d_out.p;
+    hipError_t e = pmdi_launch_cluster_logmarginal(a, cb->h->stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "calc_logmarginal launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(out, cb->d_out.p, bytes, hipMemcpyDeviceToHost, cb->h->stream));
+    HIP_TRY(hipStreamSynchronize(cb->h->stream));
+    return PMDI_OK;
+}
+
+int pmdi_cluster_stats(pmdi_cluster_batch *cb, double *out, int64_t *stride)
+{
+    if (!cb || !stride) return fail(PMDI_E_ARG, "null argument");
+    const DsetDev &d = cb->d;
+    const int D = d.D, B = cb->B;
+    const int64_t st = 1 + (d.kind == K_GAUSSIAN ? 4 * (int64_t)D : d.kind == K_CATEGORICAL ? (int64_t)D * d.L : (int64_t)D);
+    *stride = st;
+    if (!out) return PMDI_OK;
+    HIP_TRY(hipSetDevice(cb->h->cfg.device));
+    HIP_TRY(hipStreamSynchronize(cb->h->stream));
+    std::vector<int> cn((size_t)B + 1);
+    HIP_TRY(hipMemcpy(cn.data(), d.arena + d.o_cn, cn.size() * 4, hipMemcpyDeviceToHost));
+    if (d.kind == K_GAUSSIAN) {
+        std::vector<double> ml((size_t)(B + 1) * D * 2), sb(ml.size());
+        HIP_TRY(hipMemcpy(ml.data(), d.arena + d.o_ml, ml.size() * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(sb.data(), d.arena + d.o_sb, sb.size() * 8, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) {
+            double *o = out + (size_t)b * st;
+            o[0] = cn[b + 1];
+            for (int q = 0; q < D; ++q) {
+                const size_t e = ((size_t)(b + 1) * D + q) * 2;
+                o[1 + q] = ml[e]; o[1 + D + q] = sb[e]; o[1 + 2 * D + q] = ml[e + 1]; o[1 + 3 * D + q] = sb[e + 1];
+            }
+        }
+    } else if (d.kind == K_CATEGORICAL) {
+        std::vector<int> c((size_t)(B + 1) * D * d.L);
+        HIP_TRY(hipMemcpy(c.data(), d.arena + d.o_cnt, c.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) {
+            double *o = out + (size_t)b * st;
+            o[0] = cn[b + 1];
+            for (int q = 0; q < D; ++q)
+                for (int l = 0; l < d.L; ++l) o[1 + (size_t)q * d.L + l] = c[((size_t)(b + 1) * D + q) * d.L + l];
+        }
+    } else {
+        std::vector<long long> s((size_t)(B + 1) * D);
+        HIP_TRY(hipMemcpy(s.data(), d.arena + d.o_nbs, s.size() * 8, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) {
+            double *o = out + (size_t)b * st;
+            o[0] = cn[b + 1];
+            for (int q = 0; q < D; ++q) o[1 + q] = (double)s[(size_t)(b + 1) * D + q];
+        }
+    }
+    return PMDI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// pmdi_internal.h -- structures shared by the host C-ABI (pmdi_api.cpp) and
+// the device kernels (pmdi_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PMDI_KMAX_I 8
+#define PMDI_INF_I 0x7fffffff
+
+enum { K_GAUSSIAN = 0, K_CATEGORICAL = 1, K_NEGBINOM = 2 };
+enum { SITE_DRAW = 0, SITE_RESAMPLE_U = 1, SITE_RESAMPLE_SLOT = 2, SITE_PSTAR = 3, SITE_FEATSEL = 4 };
+enum { ST_NOPS = 0, ST_NRESAMPLE = 1, ST_NCLONES = 2, ST_MAXID = 3, ST_SUMCLASSES = 4 };
+
+// One dataset as the kernels see it.  Data are row-major on the device so
+// that an observation row is one contiguous, coalesced read.
+struct DsetDev {
+    int kind, D, L, flag_off;
+    const double *xf;       // [n][D]   Gaussian
+    const int *xi;          // [n][D]   Categorical (levels 1..L) / NegBinom (counts)
+    // host-built tables (so that integer-data predictives are bit-identical
+    // to a CPU evaluation with the same libm):
+    const double *gtab;     // Gaussian: G[m] = log(1/sqrt(pi)) + lgamma(m/2+1) - lgamma(m/2+1/2), m = 0..n
+    const double *lmtab;    // Gaussian logmarginal constant per cluster size m = 0..n
+    const double *lhtab;    // Categorical: LH[j] = log(j/2),    j = 0..2n+L+2
+    const double *lghtab;   // Categorical: LGH[j] = lgamma(j/2), j = 0..2(n+L)+2
+    const int *maxcol;      // Categorical: column maxima (nlevels = maxcol/2)
+    const double *lgtab;    // NegBinom: LG[m] = lgamma(m), m = 0..lgtab_len-1
+    long long lgtab_len;
+    // per-(chain, dataset) state arena: chain c lives at arena + c*stride
+    char *arena;
+    size_t stride;
+    size_t o_particle[2];   // int  [N][P]  label -> cluster id (1-based), double buffered
+    size_t o_pid;           // int  [P]     class of each particle (particle_id)
+    size_t o_sid;           // int  [P]     sstar_id
+    size_t o_newid;         // int  [P][N]  new_id[(class-1)*N + label]
+    size_t o_counts;        // int  [cap+1]
+    size_t o_ncop;          // int  [cap+1] scratch, 0 between steps
+    size_t o_firstc;        // int  [cap+1] scratch, INF between steps
+    size_t o_lp;            // double [cap+1] logprob table
+    size_t o_cn;            // int  [cap+1] cl.n
+    size_t o_ml;            // double2 [cap+1][D] (mu, lambda)
+    size_t o_sb;            // double2 [cap+1][D] (Sigma, beta)
+    size_t o_cnt;           // int  [cap+1][D][L]
+    size_t o_nbs;           // long long [cap+1][D]
+    size_t o_sstar;         // uchar [n][P]  allocation history (0-based labels)
+    size_t o_clslead;       // int  [P]   class slot -> leader particle
+    size_t o_clsval;        // int  [P]   class slot -> class value
+    size_t o_cdf;           // double [P][N+1]  per class slot: CDF, then log-increment
+    size_t o_dl;            // int  [3][P]  distinct chosen ids this step: src, dst, new n
+};
+
+struct SweepArgs {
+    int K, N, P, cap;
+    int Dmax, sumD, npairs, q1, q2, trace_on;
+    int terms_cap;          // doubles in the LDS term buffer
+    unsigned iter;
+    long long n, n1;
+    unsigned long long seed;
+    double lw_init;
+    DsetDev ds[PMDI_KMAX_I];
+    const int *s_in;            // [chain][K][n]
+    const int *order;           // [chain][n]
+    const double *Pi;           // [chain][K][N]
+    const double *logphi;       // [chain][npairs]
+    const unsigned char *flags; // [chain][sumD] or null
+    int *s_out;                 // [chain][K][n]
+    double *lw_out;             // [chain][P]
+    int *pstar;                 // [chain]
+    long long *stats;           // [chain][8]
+    int *err;                   // [chain]
+    double *trace;              // [chain][n-n1+1][2+2K]
+    // per-chain scratch
+    double *uscratch;           // [chain][P]
+    int *partstar;              // [chain][P]
+    int *kstate;                // [chain][KMAX][2]  final (max id, particle buffer) per dataset
+};
+
+struct ClusterBatchArgs {
+    DsetDev ds;        // arena/offset fields describe the batch's own storage (chain 0)
+    int B;
+    const int *rows;   // [B] 0-based
+    const unsigned char *flags; // [D] or null
+    double *out;
+};
+
+struct FeatSelArgs {
+    int K, N, sumD;
+    long long n;
+    unsigned iter;
+    unsigned long long seed;
+    DsetDev ds[PMDI_KMAX_I];
+    const int *traj;        // [chain][K][n] 0-based labels
+    double *lm;             // [chain][sumD][N]  per-label log marginals
+    int *firstpos;          // [chain][K][N]     first position of each label (INF if absent)
+    const double *fnull;    // [sumD] -(log marginal of the all-in-one cluster)
+    unsigned char *flags_out; // [chain][sumD]
+    double *prob_out;         // [chain][sumD]
+};
+
+size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T);
+hipError_t pmdi_launch_sweep(const SweepArgs &a, int n_chains, int T, hipStream_t stream);
+hipError_t pmdi_launch_cluster_add(const ClusterBatchArgs &a, hipStream_t stream);
+hipError_t pmdi_launch_cluster_logprob(const ClusterBatchArgs &a, hipStream_t stream);
+hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_t stream);
+hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream);
