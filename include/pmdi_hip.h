@@ -123,7 +123,8 @@ int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t 
                pmdi_sweep_stats *stats, double *trace);
 
 /* The same sweep on buffers already resident on the handle's device, launched
- * asynchronously on `stream` (a hipStream_t; NULL = the handle's stream).
+ * asynchronously on `stream` (a hipStream_t, used verbatim: NULL = the default
+ * stream), so that it is ordered with the caller's own work on that stream.
  * Internal encodings (no conversion pass): labels and indices 0-based int32,
  *   s_in/s_out [chain][K][n], order_obs [chain][n], Pi [chain][K][N],
  *   log1p_phi [chain][max(1,K(K-1)/2)] = log(1+Phi), feature_flag as above,
@@ -167,6 +168,10 @@ int pmdi_calc_logmarginal(pmdi_cluster_batch *cb, double *out /* B x D_k, row pe
  * Categorical n, counts[L x D col-major]; NegBinom n, Sigma[D]; returns the
  * number of doubles per cluster in *stride */
 int pmdi_cluster_stats(pmdi_cluster_batch *cb, double *out, int64_t *stride);
+
+/* Debug: per-phase shader-clock totals of the last sweep (lane 0 of the chain's workgroup);
+ * only when the environment variable PMDI_PHASE_TIMERS was set at pmdi_create. */
+int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);
 
 /* sizes a caller needs to allocate outputs */
 int pmdi_sum_D(const pmdi_handle *h);

@@ -12,8 +12,9 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libpmdi_hip.so")
-_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_kernels.hip", "pmdi_api.cpp")]
-_HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_ROOT, "include", "pmdi_hip.h")]
+_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_api.cpp")]
+_HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_PKG, "csrc", "pmdi_device.h"),
+            os.path.join(_ROOT, "include", "pmdi_hip.h")]
 
 GAUSSIAN, CATEGORICAL, NEGBINOM = 0, 1, 2
 KIND_BY_NAME = {"gaussian": GAUSSIAN, "categorical": CATEGORICAL, "negbinom": NEGBINOM,
@@ -26,7 +27,7 @@ EXPORTS = [
     "pmdi_create", "pmdi_destroy", "pmdi_last_error", "pmdi_abi_version", "pmdi_sweep",
     "pmdi_sweep_device", "pmdi_feature_select", "pmdi_export_state", "pmdi_clusters_new",
     "pmdi_clusters_free", "pmdi_cluster_add", "pmdi_calc_logprob", "pmdi_calc_logmarginal",
-    "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L",
+    "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L", "pmdi_phase_timers",
 ]
 
 
@@ -81,6 +82,13 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise PmdiError(-2, f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    if not os.environ.get("PMDI_NO_TORCH_PRELOAD"):
+        # torch bundles its own libamdhip64 (same SONAME): it must be loaded FIRST so that this
+        # library binds to the same HIP runtime and device pointers / streams can be shared
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     L.pmdi_last_error.restype = C.c_char_p
@@ -113,6 +121,8 @@ def lib():
     L.pmdi_pool_cap.argtypes = [vp]
     L.pmdi_categorical_L.restype = C.c_int
     L.pmdi_categorical_L.argtypes = [vp, i32]
+    L.pmdi_phase_timers.restype = C.c_int
+    L.pmdi_phase_timers.argtypes = [vp, i32, vp]
     _lib = L
     return L
 
@@ -224,6 +234,11 @@ class Sweeper:
         mx = np.zeros(K, dtype=np.int64)
         _check(lib().pmdi_export_state(self.h, int(chain), _ptr(particle), _ptr(counts), _ptr(cn), _ptr(mx)))
         return {"particle": particle, "counts": counts, "cluster_n": cn, "max_id": mx}
+
+    def phase_timers(self, chain=0):
+        out = np.zeros(16, dtype=np.int64)
+        _check(lib().pmdi_phase_timers(self.h, int(chain), _ptr(out)))
+        return out
 
     def clusters(self, k, B):
         return ClusterBatch(self, k, B)

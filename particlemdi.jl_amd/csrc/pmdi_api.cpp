@@ -99,13 +99,14 @@ struct pmdi_handle {
     int T = 0;
     long long cap = 0;
     int Dmax = 0, sumD = 0, npairs = 1;
-    int terms_cap = 0;
+    int terms_cap = 0, item_cap = 0, ht_size = 0, cls_lds = 0, dl_lds = 0, pid_lds = 0;
+    bool phase_on = false;
     hipStream_t stream = nullptr;
     DsetDev ds[PMDI_KMAX_I]{};
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
     bool swept = false;
@@ -149,6 +150,8 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.Dmax = h->Dmax; a.sumD = h->sumD; a.npairs = h->npairs;
     a.q1 = h->cfg.q1_mode; a.q2 = h->cfg.q2_mode;
     a.terms_cap = h->terms_cap;
+    a.item_cap = h->item_cap; a.ht_size = h->ht_size; a.cls_lds = h->cls_lds; a.dl_lds = h->dl_lds; a.pid_lds = h->pid_lds;
+    a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
     for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
@@ -168,7 +171,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -290,23 +293,31 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         if (hipMemset(arena, 0, d.stride * (size_t)cfg->n_chains) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));
     }
     h->sumD = flag_off;
-    h->T = cfg->block_threads ? cfg->block_threads : (P >= 1024 ? 1024 : (P > 256 ? 512 : 256));
+    h->T = cfg->block_threads ? cfg->block_threads : (P >= 2048 ? 1024 : (P > 256 ? 512 : 256));
     if (h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 256, 512 or 1024"));
     {
         // LDS term buffer: at least P doubles (resampling weights) and a few rows of 2*D+1
-        int tc = 4096;
+        int tc = 2048;
         if (tc < P) tc = P;
         if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
         h->terms_cap = tc;
+        h->item_cap = 512; h->ht_size = 1024; h->cls_lds = 256; h->dl_lds = 256;
+        h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         SweepArgs a;
+        h->pid_lds = 1;
         fill_sweep_common(h, a);
+        if (pmdi_sweep_lds_bytes(a, h->T) > 150 * 1024) {      // class ids of K*P particles do not fit: keep them in global memory
+            h->pid_lds = 0;
+            fill_sweep_common(h, a);
+        }
         if (pmdi_sweep_lds_bytes(a, h->T) > 160 * 1024)
             return bail(fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, h->T)));
     }
     const int C = cfg->n_chains;
     if ((rc = h->d_usc.ensure((size_t)C * P * 8)) || (rc = h->d_partstar.ensure((size_t)C * P * 4)) ||
         (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
-        (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)))
+        (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
+        (rc = h->d_phase.ensure((size_t)C * 16 * 8)))
         return bail(rc);
 
     // null-cluster marginal (src/pmdi.jl:120-128): all rows in one cluster, all features on
@@ -337,6 +348,16 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     return PMDI_OK;
 }
 
+int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16)
+{
+    if (!h || !out16 || chain < 0 || chain >= h->cfg.n_chains) return fail(PMDI_E_ARG, "bad argument");
+    if (!h->phase_on) return fail(PMDI_E_STATE, "set PMDI_PHASE_TIMERS=1 before pmdi_create");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, (char *)h->d_phase.p + (size_t)chain * 16 * 8, 16 * 8, hipMemcpyDeviceToHost));
+    return PMDI_OK;
+}
+
 int pmdi_sum_D(const pmdi_handle *h) { return h ? h->sumD : 0; }
 int64_t pmdi_pool_cap(const pmdi_handle *h) { return h ? h->cap : 0; }
 int pmdi_categorical_L(const pmdi_handle *h, int32_t k) { return (h && k >= 0 && k < h->cfg.K) ? h->ds[k].L : 0; }
@@ -358,7 +379,7 @@ int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const i
     a.err = err ? err : (int *)h->d_err.p;
     a.trace = nullptr; a.trace_on = 0;
     a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
-    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t st = (hipStream_t)stream;   // used verbatim: NULL is the device's default (null) stream
     hipError_t e = pmdi_launch_sweep(a, h->cfg.n_chains, h->T, st);
     if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
     h->swept = true; h->last_n1 = n1;

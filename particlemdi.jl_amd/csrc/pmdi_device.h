@@ -1,0 +1,247 @@
+// pmdi_device.h -- device helpers shared by the sweep kernel (pmdi_sweep.hip) and the
+// unit / feature-selection kernels (pmdi_kernels.hip).  Compile with -ffp-contract=off.
+// Reference lines are cited as file:line relative to /root/reference.
+#pragma once
+#include "pmdi_internal.h"
+
+namespace pmdi_dev {
+
+// ---------------------------------------------------------------------------
+// Counter-based RNG (specification shared with oracle/pmdi_oracle.c):
+// Philox4x32-10, key = (seed lo, seed hi), ctr = (p, pos, site<<16|k, iter).
+__device__ __forceinline__ double uniform01(unsigned long long seed, unsigned iter, unsigned pos,
+                                            unsigned k, unsigned p, unsigned site)
+{
+    unsigned c0 = p, c1 = pos, c2 = (site << 16) | k, c3 = iter;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    unsigned long long m = ((unsigned long long)(c0 >> 5) << 26) | (unsigned long long)(c1 >> 6);
+    return (double)m * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------
+struct KS {  // pointers of one (chain, dataset)
+    int *part[2];
+    int *pid, *sid, *newid, *counts, *ncop, *firstc, *cn, *clslead, *clsval, *dl;
+    double *lp, *cdf;
+    double2 *ml, *sb;
+    int *cnt;
+    long long *nbs;
+    unsigned char *sstar;
+};
+
+__device__ __forceinline__ KS make_ks(const DsetDev &d, int chain)
+{
+    KS s;
+    char *b = d.arena + (size_t)chain * d.stride;
+    s.part[0] = (int *)(b + d.o_particle[0]);
+    s.part[1] = (int *)(b + d.o_particle[1]);
+    s.pid = (int *)(b + d.o_pid);
+    s.sid = (int *)(b + d.o_sid);
+    s.newid = (int *)(b + d.o_newid);
+    s.counts = (int *)(b + d.o_counts);
+    s.ncop = (int *)(b + d.o_ncop);
+    s.firstc = (int *)(b + d.o_firstc);
+    s.lp = (double *)(b + d.o_lp);
+    s.cn = (int *)(b + d.o_cn);
+    s.ml = (double2 *)(b + d.o_ml);
+    s.sb = (double2 *)(b + d.o_sb);
+    s.cnt = (int *)(b + d.o_cnt);
+    s.nbs = (long long *)(b + d.o_nbs);
+    s.sstar = (unsigned char *)(b + d.o_sstar);
+    s.clslead = (int *)(b + d.o_clslead);
+    s.clsval = (int *)(b + d.o_clsval);
+    s.cdf = (double *)(b + d.o_cdf);
+    s.dl = (int *)(b + d.o_dl);
+    return s;
+}
+
+// ---------------------------------------------------------------------------
+// Block-level primitives (64-wide waves).
+template <int T>
+__device__ __forceinline__ unsigned long long block_excl_scan(unsigned long long v,
+                                                              unsigned long long &total,
+                                                              unsigned long long *scr)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        unsigned long long t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) scr[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) {
+        unsigned long long s = scr[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+// Exclusive ranks of up to three 1-bit flags over the block in thread order, by wave ballots:
+// returns packed (f0 | f1<<20 | f2<<40) exclusive prefix and block total, like block_excl_scan.
+template <int T>
+__device__ __forceinline__ unsigned long long block_flag_scan(bool f0, bool f1, bool f2,
+                                                              unsigned long long &total,
+                                                              unsigned long long *scr)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2);
+    const unsigned long long mine = (unsigned long long)__popcll(b0 & lt) |
+                                    ((unsigned long long)__popcll(b1 & lt) << 20) |
+                                    ((unsigned long long)__popcll(b2 & lt) << 40);
+    if (lane == 0)
+        scr[wave] = (unsigned long long)__popcll(b0) | ((unsigned long long)__popcll(b1) << 20) |
+                    ((unsigned long long)__popcll(b2) << 40);
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) {
+        const unsigned long long v = scr[w];
+        if (w < wave) base += v;
+        tot += v;
+    }
+    __syncthreads();
+    total = tot;
+    return base + mine;
+}
+
+template <int T>
+__device__ __forceinline__ double block_max(double v, double *scr)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double t = __shfl_xor(v, off);
+        v = (t > v) ? t : v;
+    }
+    if (lane == 0) scr[wave] = v;
+    __syncthreads();
+    double m = scr[0];
+#pragma unroll
+    for (int w = 1; w < T / 64; ++w) { double t = scr[w]; m = (t > m) ? t : m; }
+    __syncthreads();
+    return m;
+}
+
+template <int T>
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *scr)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+    }
+    if (lane == 0) { scr[wave] = a; scr[16 + wave] = b; }
+    __syncthreads();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) { sa += scr[w]; sb += scr[16 + w]; }
+    __syncthreads();
+    a = sa; b = sb;
+}
+
+// Lanes of a wave holding equal `key` (among `valid` lanes) elect the lowest
+// lane as group leader; returns true on the leader with the group's size.
+__device__ __forceinline__ bool wave_group(int key, bool valid, int &count)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(valid);
+    bool leader = false;
+    count = 0;
+    while (active) {
+        int l0 = __ffsll((long long)active) - 1;
+        int k0 = __shfl(key, l0);
+        unsigned long long m = __ballot(valid && key == k0);
+        if (lane == l0) { leader = true; count = __popcll(m); }
+        active &= ~m;
+    }
+    return leader;
+}
+
+// Julia Base.accumulate_pairwise! (base/accumulate.jl), the algorithm behind
+// cumsum(::Vector{Float64}) at src/misc.jl:29: in place on c[0..n).  Run by
+// one lane; the recursion is unrolled onto a small explicit stack.
+__device__ void jl_cumsum_inplace(double *c, int n)
+{
+    if (n <= 1) return;
+    const double v1 = c[0];
+    int f_i1[24], f_n[24], f_stage[24];
+    double f_s[24], f_left[24];
+    int sp = 0;
+    f_i1[0] = 1; f_n[0] = n - 1; f_s[0] = v1; f_stage[0] = 0; f_left[0] = 0.0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        const int i1 = f_i1[sp], nn = f_n[sp];
+        const double s = f_s[sp];
+        if (nn < 128) {
+            double s_ = c[i1];
+            c[i1] = s + s_;
+            for (int i = i1 + 1; i < i1 + nn; ++i) {
+                s_ = s_ + c[i];
+                c[i] = s + s_;
+            }
+            ret = s_;
+            --sp;
+        } else if (f_stage[sp] == 0) {
+            f_stage[sp] = 1;
+            ++sp;
+            f_i1[sp] = i1; f_n[sp] = nn >> 1; f_s[sp] = s; f_stage[sp] = 0;
+        } else if (f_stage[sp] == 1) {
+            f_left[sp] = ret;
+            f_stage[sp] = 2;
+            const int n2 = nn >> 1;
+            ++sp;
+            f_i1[sp] = i1 + n2; f_n[sp] = nn - n2; f_s[sp] = s + ret; f_stage[sp] = 0;
+        } else {
+            ret = f_left[sp] + ret;
+            --sp;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-type arithmetic, restating the reference expression by expression.
+
+// cluster_add!(::GaussianCluster): gaussian_cluster.jl:54-66 (one feature)
+__device__ __forceinline__ void gauss_add(double x, int nnew, double2 &ml, double2 &sb)
+{
+    const double n = (double)nnew;
+    sb.x = sb.x + x;
+    const double d = x - ml.x;
+    sb.y = sb.y + ((double)(nnew - 1) + 0.001) * (d * d) / (2.0 * (n + 0.001));
+    ml.x = sb.x / (n + 0.001);
+    ml.y = ((0.5 * n + 0.5) * (n + 0.001)) / (sb.y * (n + 1.001));
+}
+
+// the two per-feature terms of calc_logprob(::GaussianCluster): gaussian_cluster.jl:45-48
+__device__ __forceinline__ void gauss_terms(double x, double n, double2 ml, double &ta, double &tb)
+{
+    ta = 0.5 * log(ml.y / (n + 1.0));
+    const double d = x - ml.x;
+    tb = (0.5 * n + 1.0) * log(1.0 + (1.0 / (n + 1.0)) * (d * d) * ml.y);
+}
+
+// calc_logprob(::NegBinomCluster) per-feature term: negbinom_cluster.jl:33-37;
+// loggamma of integers comes from the host-built table LG[m] = lgamma(m)
+__device__ __forceinline__ double negbin_term(const double *lg, long long n, long long x, long long S)
+{
+    return lg[1 + n + 1] + lg[1 + x + S] + lg[1 + n + 1 + S] - lg[1 + n + 1 + 1 + x + S] -
+           lg[1 + n] - lg[1 + S];
+}
+}  // namespace pmdi_dev

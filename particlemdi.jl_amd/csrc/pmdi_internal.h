@@ -53,6 +53,11 @@ struct SweepArgs {
     int K, N, P, cap;
     int Dmax, sumD, npairs, q1, q2, trace_on;
     int terms_cap;          // doubles in the LDS term buffer
+    int item_cap;           // (class, label) items a step may have to use the LDS tables
+    int ht_size;            // entries of each LDS hash table (power of two, >= 2*item_cap)
+    int cls_lds;            // class-list slots per dataset kept in LDS
+    int dl_lds;             // distinct-chosen-cluster list entries kept in LDS
+    int pid_lds;            // 1: particle class ids [K][P] live in LDS
     unsigned iter;
     long long n, n1;
     unsigned long long seed;
@@ -73,6 +78,7 @@ struct SweepArgs {
     double *uscratch;           // [chain][P]
     int *partstar;              // [chain][P]
     int *kstate;                // [chain][KMAX][2]  final (max id, particle buffer) per dataset
+    long long *phase;           // [chain][16] per-phase shader-clock totals of lane 0, or null
 };
 
 struct ClusterBatchArgs {

@@ -1,0 +1,959 @@
+// pmdi_sweep.hip -- the conditional-SMC sweep of one Gibbs iteration as ONE persistent
+// kernel for gfx950 (CDNA4).  Compile with -ffp-contract=off: the floating-point expression
+// order is the reference's and must not be contracted into FMAs.
+//
+// Mapping (DESIGN.md has the full account):
+//   * one workgroup = one Gibbs chain, resident for the whole sweep (known-prefix build, the
+//     n_s x K strictly sequential steps, resampling, particle pick): a kernel boundary per
+//     step (>= 1.5 us) would cost more than a step's work;
+//   * one particle per lane for everything per particle (allocation draw, weight update,
+//     class and copy-on-write bookkeeping);
+//   * the reference's de-duplication is kept and tightened: log-predictives are evaluated only
+//     for the clusters a particle-class leader can reach (lanes = cluster x feature), mutation
+//     CDFs once per class (lanes = class x label inside a wave, shuffles);
+//   * the per-step working set lives in LDS: observation row, Pi, log-weights, class ids and
+//     class lists, the needed-cluster logprob table, per-class CDFs, a hash table for the
+//     chosen-cluster census, scan/reduction scratch.  HBM/L2 holds the bulk state only: the
+//     cluster-statistics pool, the label->cluster table and the allocation history.  When a
+//     step's working set outgrows the LDS structures (burn-in: hundreds of classes) the step
+//     falls back to per-id tables in global memory -- same results, slower.
+//
+// Reference lines are cited as file:line relative to /root/reference.
+#include "pmdi_device.h"
+
+using namespace pmdi_dev;
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Open-addressing hash table in LDS: key = cluster id (0 = empty), two payload words.
+struct HT {
+    int *key, *a, *b;
+    unsigned mask;
+};
+
+__device__ __forceinline__ unsigned ht_hash(int id) { return ((unsigned)id * 2654435761u) >> 12; }
+
+// slot of `id`, creating it if absent (won = this lane created it); -1 if too crowded
+__device__ __forceinline__ int ht_insert(const HT &h, int id, bool &won, int maxprobe)
+{
+    unsigned s = ht_hash(id) & h.mask;
+    won = false;
+    for (int pr = 0; pr < maxprobe; ++pr) {
+        const int k = __hip_atomic_load(&h.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == id) return (int)s;
+        if (k == 0) {
+            const int old = atomicCAS(&h.key[s], 0, id);
+            if (old == 0) { won = true; return (int)s; }
+            if (old == id) return (int)s;
+        }
+        s = (s + 1) & h.mask;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ int ht_find(const HT &h, int id)
+{
+    unsigned s = ht_hash(id) & h.mask;
+    for (unsigned pr = 0; pr <= h.mask; ++pr) {
+        if (h.key[s] == id) return (int)s;
+        s = (s + 1) & h.mask;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
+    size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
+        need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, kmaxid, kncls, kcur, knflag, lab, misc, ph,
+        fl, news, total;
+};
+
+__host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
+{
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+    const int Dp = (a.Dmax + 15) & ~15;
+    c.xs = take((size_t)a.Dmax * 8);
+    c.pis = take((size_t)a.K * a.N * 8);
+    c.lw = take((size_t)a.P * 8);
+    c.term = take((size_t)a.terms_cap * 8);
+    c.lpl = take((size_t)a.item_cap * 8);
+    c.cdf = take((size_t)(a.item_cap + a.item_cap / 2 + 2) * 8);
+    c.scan = take(16 * 8);
+    c.red = take(32 * 8);
+    c.pid = take(a.pid_lds ? (size_t)a.K * a.P * 4 : 0);
+    c.sid = take((size_t)a.P * 4);
+    c.kv = take((size_t)a.P * 4);
+    c.lead_of = take((size_t)(a.P + 1) * 4);
+    c.slot_of = take((size_t)(a.P + 1) * 4);
+    c.cl_lead = take((size_t)a.K * a.cls_lds * 4);
+    c.cl_val = take((size_t)a.K * a.cls_lds * 4);
+    c.need = take((size_t)a.item_cap * 4);
+    c.need_slot = take((size_t)a.item_cap * 4);
+    c.item_id = take((size_t)a.item_cap * 4);
+    c.dl = take((size_t)3 * a.dl_lds * 4);
+    c.dl_slot = take((size_t)a.dl_lds * 4);
+    c.h1k = take((size_t)a.ht_size * 4);
+    c.h1a = take((size_t)a.ht_size * 4);
+    c.h2k = take((size_t)a.ht_size * 4);
+    c.h2a = take((size_t)a.ht_size * 4);
+    c.h2b = take((size_t)a.ht_size * 4);
+    c.kmaxid = take(PMDI_KMAX_I * 4);
+    c.kncls = take(PMDI_KMAX_I * 4);
+    c.kcur = take(PMDI_KMAX_I * 4);
+    c.knflag = take(PMDI_KMAX_I * 4);
+    c.lab = take(256 * 3 * 4);
+    c.misc = take(16 * 4);
+    c.ph = take(16 * 8);
+    c.fl = take((size_t)a.K * Dp);
+    c.news = take((size_t)a.K * a.P);
+    c.total = o;
+}
+
+struct Sh {
+    double *xs, *pis, *lw, *term, *lpl, *cdf, *red;
+    unsigned long long *scan;
+    int *pid, *sid, *kv, *lead_of, *slot_of, *cl_lead, *cl_val, *need, *need_slot, *item_id, *dl, *dl_slot;
+    HT h1, h2;
+    int *kmaxid, *kncls, *kcur, *knflag, *lab, *misc;
+    long long *ph;
+    unsigned char *fl, *news;
+};
+
+enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2 };
+
+// class list of dataset k: slot r -> leader particle / class value.  The first cls_lds slots
+// live in LDS, the rest (burn-in only) in global memory.
+struct ClsList {
+    int *l_lead, *l_val, *g_lead, *g_val;
+    int cap;
+    __device__ __forceinline__ int lead(int r) const { return r < cap ? l_lead[r] : g_lead[r]; }
+    __device__ __forceinline__ int val(int r) const { return r < cap ? l_val[r] : g_val[r]; }
+    __device__ __forceinline__ void set(int r, int p, int v) const
+    {
+        if (r < cap) { l_lead[r] = p; l_val[r] = v; } else { g_lead[r] = p; g_val[r] = v; }
+    }
+};
+
+// Rebuild the class list from pid[]: leader = lowest particle of each class (the particle
+// whose CDF the reference caches in fprob_dict, src/pmdi.jl:225-248).  lead_of must be INF
+// for every class value on entry; it is INF again on exit.  Returns the number of classes.
+template <int T>
+__device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &cl, const Sh &sh, int P)
+{
+    const int tid = threadIdx.x;
+    for (int pb = 0; pb < P; pb += T) {
+        const int p = pb + tid;
+        const bool valid = p < P;
+        const int cls = valid ? pidk[p] : 0;
+        int cnt;
+        if (wave_group(cls, valid, cnt)) atomicMin(&sh.lead_of[cls], p);
+    }
+    __syncthreads();
+    unsigned long long carry = 0;
+    for (int pb = 0; pb < P; pb += T) {
+        const int p = pb + tid;
+        const bool valid = p < P;
+        const int cls = valid ? pidk[p] : 0;
+        const bool isl = valid && sh.lead_of[cls] == p;
+        unsigned long long tot;
+        const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, sh.scan) + carry;
+        if (isl) { cl.set((int)ex, p, cls); sh.slot_of[cls] = (int)ex; }
+        carry += tot;
+    }
+    __syncthreads();
+    for (int r = tid; r < (int)carry; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
+    return (int)carry;
+}
+
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chain = blockIdx.x;
+    const int K = a.K, N = a.N, P = a.P, cap = a.cap;
+    const long long n = a.n, n1 = a.n1;
+    const unsigned long long seed = a.seed + (unsigned long long)chain;
+    const unsigned iter = a.iter;
+    const int Dp = (a.Dmax + 15) & ~15;
+    const int H = a.ht_size;
+
+    Sh sh;
+    {
+        Carve c;
+        carve_lds(a, c);
+        sh.xs = (double *)(smem + c.xs); sh.pis = (double *)(smem + c.pis); sh.lw = (double *)(smem + c.lw);
+        sh.term = (double *)(smem + c.term); sh.lpl = (double *)(smem + c.lpl); sh.cdf = (double *)(smem + c.cdf);
+        sh.scan = (unsigned long long *)(smem + c.scan); sh.red = (double *)(smem + c.red);
+        sh.pid = (int *)(smem + c.pid); sh.sid = (int *)(smem + c.sid); sh.kv = (int *)(smem + c.kv);
+        sh.lead_of = (int *)(smem + c.lead_of); sh.slot_of = (int *)(smem + c.slot_of);
+        sh.cl_lead = (int *)(smem + c.cl_lead); sh.cl_val = (int *)(smem + c.cl_val);
+        sh.need = (int *)(smem + c.need); sh.need_slot = (int *)(smem + c.need_slot);
+        sh.item_id = (int *)(smem + c.item_id); sh.dl = (int *)(smem + c.dl); sh.dl_slot = (int *)(smem + c.dl_slot);
+        sh.h1.key = (int *)(smem + c.h1k); sh.h1.a = (int *)(smem + c.h1a); sh.h1.b = nullptr; sh.h1.mask = (unsigned)H - 1;
+        sh.h2.key = (int *)(smem + c.h2k); sh.h2.a = (int *)(smem + c.h2a); sh.h2.b = (int *)(smem + c.h2b); sh.h2.mask = (unsigned)H - 1;
+        sh.kmaxid = (int *)(smem + c.kmaxid); sh.kncls = (int *)(smem + c.kncls); sh.kcur = (int *)(smem + c.kcur); sh.knflag = (int *)(smem + c.knflag);
+        sh.lab = (int *)(smem + c.lab); sh.misc = (int *)(smem + c.misc); sh.ph = (long long *)(smem + c.ph);
+        sh.fl = smem + c.fl; sh.news = smem + c.news;
+    }
+
+    const int *s_in = a.s_in + (size_t)chain * K * n;
+    const int *order = a.order + (size_t)chain * n;
+    const double *Pi = a.Pi + (size_t)chain * K * N;
+    const double *logphi = a.logphi + (size_t)chain * a.npairs;
+    const unsigned char *flags = a.flags ? a.flags + (size_t)chain * a.sumD : nullptr;
+    double *usc = a.uscratch + (size_t)chain * P;
+    int *pstar_raw = a.partstar + (size_t)chain * P;
+
+    long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
+    long long ph_last = 0;
+    int ph_cur = 0;
+#define PH(i_)                                                                  \
+    do {                                                                        \
+        if (a.phase && tid == 0) {                                              \
+            const long long t_ = clock64();                                     \
+            sh.ph[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_);         \
+        }                                                                       \
+    } while (0)
+    if (tid < 16) { sh.ph[tid] = 0; sh.misc[tid] = 0; }
+    long long ph_t0 = 0, ph_r0 = 0;
+    if (a.phase && tid == 0) { ph_last = clock64(); ph_t0 = ph_last; ph_r0 = wall_clock64(); }
+
+    for (int p = tid; p < P; p += T) sh.lw[p] = a.lw_init;
+    for (int c = tid; c <= P; c += T) { sh.lead_of[c] = PMDI_INF_I; sh.slot_of[c] = 0; }
+    for (int e = tid; e < H; e += T) { sh.h1.key[e] = 0; sh.h1.a[e] = 0; sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+
+    // ---- reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207) ----
+    for (int k = 0; k < K; ++k) {
+        const DsetDev &d = a.ds[k];
+        const KS s = make_ks(d, chain);
+        const int D = d.D;
+        int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
+        unsigned char *flk = sh.fl + (size_t)k * Dp;
+        for (int idx = tid; idx <= cap; idx += T) { s.counts[idx] = 0; s.ncop[idx] = 0; s.firstc[idx] = PMDI_INF_I; }
+        for (int idx = tid; idx < N * P; idx += T) { s.newid[idx] = 0; s.part[0][idx] = 1; }
+        for (int p = tid; p < P; p += T) pidk[p] = 1;
+        for (int u = tid; u < 256; u += T) { sh.lab[u] = PMDI_INF_I; sh.lab[256 + u] = 0; sh.lab[512 + u] = 0; }
+        for (int q = tid; q < D; q += T) flk[q] = flags ? flags[d.flag_off + q] : (unsigned char)1;
+        for (int nn = tid; nn < N; nn += T) sh.pis[k * N + nn] = Pi[(size_t)k * N + nn];
+        __syncthreads();
+        // unique(s[order_obs[1:n1-1], k]) in first-appearance order (:192)
+        for (long long j = tid; j < n1 - 1; j += T) {
+            const int u = s_in[(size_t)k * n + order[j]];
+            atomicMin(&sh.lab[u], (int)j);
+            atomicAdd(&sh.lab[512 + u], 1);
+        }
+        __syncthreads();
+        if (tid < N) {
+            const int fp = sh.lab[tid];
+            if (fp != PMDI_INF_I) {
+                int r = 0;
+                for (int v = 0; v < N; ++v) r += (sh.lab[v] < fp) ? 1 : 0;
+                sh.lab[256 + tid] = 2 + r;        // cluster id of label u (:197)
+            }
+        }
+        __syncthreads();
+        int nu = 0;
+        for (int v = 0; v < N; ++v) nu += (sh.lab[v] != PMDI_INF_I) ? 1 : 0;
+        // particle[u, :, k] .= id ; counts (:195-198)
+        for (int idx = tid; idx < N * P; idx += T) {
+            const int id = sh.lab[256 + idx / P];
+            if (id) s.part[0][idx] = id;
+        }
+        if (tid < N && sh.lab[256 + tid]) s.counts[sh.lab[256 + tid]] = P;
+        if (tid == 0) { s.counts[1] = P * N - nu * P; s.cn[1] = 0; }
+        if (tid < N && sh.lab[256 + tid]) s.cn[sh.lab[256 + tid]] = sh.lab[512 + tid];
+        // fresh clusters 1..nu+1 (:189,:194)
+        if (d.kind == K_GAUSSIAN) {
+            for (int it = tid; it < (nu + 1) * D; it += T) {
+                s.ml[D + it] = make_double2(0.0, 1.0);
+                s.sb[D + it] = make_double2(0.0, 0.5);
+            }
+        } else if (d.kind == K_CATEGORICAL) {
+            for (int it = tid; it < (nu + 1) * D * d.L; it += T) s.cnt[(size_t)D * d.L + it] = 0;
+        } else {
+            for (int it = tid; it < (nu + 1) * D; it += T) s.nbs[D + it] = 0;
+        }
+        __syncthreads();
+        // the first n1-1 shuffled observations join their previous cluster, sequentially in
+        // shuffled order (:201-206); lanes = (label, feature)
+        for (int it = tid; it < N * D; it += T) {
+            const int u = it / D, q = it - u * D;
+            const int id = sh.lab[256 + u];
+            if (!id || !flk[q]) continue;
+            if (d.kind == K_GAUSSIAN) {
+                double2 ml = make_double2(0.0, 1.0), sb = make_double2(0.0, 0.5);
+                int c = 0;
+                for (long long j = 0; j < n1 - 1; ++j) {
+                    const int i = order[j];
+                    if (s_in[(size_t)k * n + i] != u) continue;
+                    ++c;
+                    gauss_add(d.xf[(size_t)i * D + q], c, ml, sb);
+                }
+                s.ml[(size_t)id * D + q] = ml;
+                s.sb[(size_t)id * D + q] = sb;
+            } else if (d.kind == K_CATEGORICAL) {
+                int *cn_ = s.cnt + ((size_t)id * D + q) * d.L;
+                for (long long j = 0; j < n1 - 1; ++j) {
+                    const int i = order[j];
+                    if (s_in[(size_t)k * n + i] != u) continue;
+                    cn_[d.xi[(size_t)i * D + q] - 1] += 1;
+                }
+            } else {
+                long long S = 0;
+                for (long long j = 0; j < n1 - 1; ++j) {
+                    const int i = order[j];
+                    if (s_in[(size_t)k * n + i] != u) continue;
+                    S += d.xi[(size_t)i * D + q];
+                }
+                s.nbs[(size_t)id * D + q] = S;
+            }
+        }
+        if (tid == 0) {
+            sh.kmaxid[k] = nu + 1;
+            sh.kncls[k] = 1;
+            sh.kcur[k] = 0;
+            int nf = 0;
+            for (int q = 0; q < D; ++q) nf += flk[q];
+            sh.knflag[k] = nf;
+            const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
+            cl.set(0, 0, 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- the sweep: src/pmdi.jl:209-342 ----
+    PH(1);
+    int failed = 0;
+    bool lw_uniform = true;     // every particle holds the same log-weight (then ESS == P exactly)
+    int i_next = order[n1 - 1];
+    for (long long pos = n1 - 1; pos < n && !failed; ++pos) {
+        const int i = i_next;
+        if (pos + 1 < n) i_next = order[pos + 1];
+        for (int k = 0; k < K && !failed; ++k) {
+            const DsetDev &d = a.ds[k];
+            const KS s = make_ks(d, chain);
+            const int D = d.D;
+            const int maxid = sh.kmaxid[k];
+            const int ncls = sh.kncls[k];
+            const int cur = sh.kcur[k];
+            int *part = s.part[cur];
+            int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
+            const unsigned char *flk = sh.fl + (size_t)k * Dp;
+            const double *pik = sh.pis + k * N;
+            const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
+            const int items = ncls * N;
+            const bool small = items <= a.item_cap;
+            if (ncls != 1) lw_uniform = false;
+
+            PH(1);
+            // the observation row: issue the load now, land it in LDS after the needed-id pass
+            double xr = 0.0;
+            int xri = 0;
+            if (tid < D) {
+                if (d.kind == K_GAUSSIAN) xr = d.xf[(size_t)i * D + tid]; else xri = d.xi[(size_t)i * D + tid];
+            }
+            // slot_of is shared by the K datasets: rebuild it from this dataset's class list
+            for (int r = tid; r < ncls; r += T) sh.slot_of[cl.val(r)] = r;
+            if (tid == 0) sh.misc[M_OVF] = 0;
+
+            // -- A1: which clusters can a class leader reach?  (the reference evaluates every
+            // id 1..max at :218-220, but only these entries are ever read at :232)
+            if (small) {
+                for (int w = tid; w < items; w += T) {
+                    const int r = w / N, nn = w - r * N;
+                    const int id = part[nn * P + cl.lead(r)];
+                    sh.item_id[w] = id;
+                    bool won;
+                    const int slot = ht_insert(sh.h1, id, won, H);   // cannot fail: items <= ht_size/2
+                    if (won) {
+                        const int ps = atomicAdd(&sh.misc[M_NEED], 1);
+                        sh.need[ps] = id; sh.need_slot[ps] = slot; sh.h1.a[slot] = ps;
+                    }
+                }
+            }
+            if (tid < D) {
+                if (d.kind == K_GAUSSIAN) sh.xs[tid] = xr; else ((int *)sh.xs)[tid] = xri;
+            }
+            for (int q = T + tid; q < D; q += T) {
+                if (d.kind == K_GAUSSIAN) sh.xs[q] = d.xf[(size_t)i * D + q]; else ((int *)sh.xs)[q] = d.xi[(size_t)i * D + q];
+            }
+            __syncthreads();
+            const int nneed = small ? sh.misc[M_NEED] : maxid;
+            const int nflag = sh.knflag[k];
+
+            // -- A2/A3: log-predictive of the needed clusters.  Lanes = (cluster, feature) for
+            // the per-feature terms, then one lane per cluster adds them in feature order
+            // (bit-identical to the sequential loops of calc_logprob).
+            {
+                const int RS = 2 * D + 1, D1 = D + 1;
+                int CH = a.terms_cap / RS;
+                if (CH < 1) CH = 1;
+                for (int j0 = 0; j0 < nneed; j0 += CH) {
+                    const int nid = min(CH, nneed - j0);
+                    PH(2);
+                    for (int it = tid; it < nid * D1; it += T) {
+                        const int il = it / D1, q = it - il * D1;
+                        const int id = small ? sh.need[j0 + il] : 1 + j0 + il;
+                        const int cn = s.cn[id];
+                        if (q == D) {   // the per-cluster prefix: gaussian_cluster.jl:38-40
+                            if (d.kind == K_GAUSSIAN) sh.term[il * RS + 2 * D] = (double)nflag * d.gtab[cn];
+                            continue;
+                        }
+                        if (!flk[q]) continue;
+                        double ta = 0.0, tb = 0.0;
+                        if (d.kind == K_GAUSSIAN) {
+                            gauss_terms(sh.xs[q], (double)cn, s.ml[(size_t)id * D + q], ta, tb);
+                        } else if (d.kind == K_CATEGORICAL) {
+                            const int x = ((const int *)sh.xs)[q];
+                            ta = d.lhtab[d.maxcol[q] + 2 * cn];                 // log(nlevels_q + n)
+                            const int c = s.cnt[((size_t)id * D + q) * d.L + (x - 1)];
+                            tb = (cn == 0) ? d.lhtab[1] : d.lhtab[2 * c + 1];   // log(0.5 + counts)
+                        } else {
+                            const int x = ((const int *)sh.xs)[q];
+                            ta = negbin_term(d.lgtab, cn, x, s.nbs[(size_t)id * D + q]);
+                        }
+                        sh.term[il * RS + 2 * q] = ta;
+                        sh.term[il * RS + 2 * q + 1] = tb;
+                    }
+                    __syncthreads();
+                    PH(3);
+                    for (int il = tid; il < nid; il += T) {
+                        const double *t = sh.term + il * RS;
+                        double out;
+                        if (d.kind == K_GAUSSIAN) {
+                            out = t[2 * D];
+                            if (nflag == D) {   // all features on: fetch 8 features' terms, then add in order
+                                for (int q0 = 0; q0 < D; q0 += 8) {
+                                    double ra[8], rb[8];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        const int q = min(q0 + u, D - 1);
+                                        ra[u] = t[2 * q]; rb[u] = t[2 * q + 1];
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u)
+                                        if (q0 + u < D) { out += ra[u]; out -= rb[u]; }
+                                }
+                            } else {
+                                for (int q = 0; q < D; ++q)
+                                    if (flk[q]) { out += t[2 * q]; out -= t[2 * q + 1]; }
+                            }
+                        } else if (d.kind == K_CATEGORICAL) {
+                            double acc = 0.0;                                  // categorical_cluster.jl:30
+                            for (int q = 0; q < D; ++q) if (flk[q]) acc += t[2 * q];
+                            out = -acc;
+                            for (int q = 0; q < D; ++q) if (flk[q]) out += t[2 * q + 1];
+                        } else {
+                            out = 0.0;                                         // negbinom_cluster.jl:25
+                            for (int q = 0; q < D; ++q) if (flk[q]) out += t[2 * q];
+                        }
+                        if (small) sh.lpl[j0 + il] = out; else s.lp[1 + j0 + il] = out;
+                    }
+                    __syncthreads();
+                }
+            }
+
+            // -- B: mutation CDF per particle class (:231-248): lanes = (class, label) inside a
+            // wave; max / cumsum / normalise by shuffles.  The cumsum follows Julia's
+            // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
+            PH(4);
+            double *cdfp = small ? sh.cdf : s.cdf;
+            {
+                const int G = 64 / N;
+                const int g = lane / N, nn = lane - g * N;
+                const int gbase = (g < G) ? g * N : 0;
+                double *wv = sh.term + wave * 128;      // this wave's exchange area (terms are dead here)
+                for (int r0 = 0; r0 < ncls; r0 += (T / 64) * G) {
+                    if (r0 + wave * G >= ncls) break;          // wave-uniform: nothing left for this wave
+                    const int r = r0 + wave * G + g;
+                    const bool valid = (g < G) && (r < ncls);
+                    double v = 0.0;
+                    if (valid) {
+                        if (small) v = sh.lpl[sh.h1.a[ht_find(sh.h1, sh.item_id[r * N + nn])]];
+                        else v = s.lp[part[nn * P + cl.lead(r)]];
+                    }
+                    wv[lane] = v;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    double m = v;
+                    for (int j = 0; j < N; ++j) {
+                        const double t = wv[gbase + j];
+                        m = (t > m) ? t : m;
+                    }
+                    double e = v - m;
+                    e = exp(e);
+                    e = e * pik[nn];
+                    wv[64 + lane] = e;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const double e0 = wv[64 + gbase];
+                    double s_ = 0.0;
+                    for (int j = 1; j < N; ++j) {
+                        const double t = wv[64 + gbase + j];
+                        if (j <= nn) s_ = (j == 1) ? t : s_ + t;
+                    }
+                    const double c = (nn == 0) ? e : e0 + s_;
+                    __builtin_amdgcn_wave_barrier();
+                    wv[lane] = c;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const double fN = wv[gbase + N - 1];
+                    if (valid) {
+                        cdfp[(size_t)r * (N + 1) + nn] = c / fN;
+                        if (nn == N - 1) cdfp[(size_t)r * (N + 1) + N] = log(fN) + m;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+
+            // -- C: allocation draw (:251-265), class key, chosen-cluster census
+            PH(5);
+            if (small) {
+                for (int j = tid; j < nneed; j += T) { const int sl = sh.need_slot[j]; sh.h1.key[sl] = 0; sh.h1.a[sl] = 0; }
+                if (tid == 0) sh.misc[M_NEED] = 0;
+            }
+            for (int pb = 0; pb < P; pb += T) {
+                const int p = pb + tid;
+                const bool valid = p < P;
+                int ns = 0, c = 0, key = 0;
+                bool fresh = false;
+                if (valid) {
+                    const int cls = pidk[p];
+                    const double *row = cdfp + (size_t)sh.slot_of[cls] * (N + 1);
+                    if (p != 0) {
+                        const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                        for (int t = 0; t < N - 1; ++t) {
+                            if (row[ns] > u) break;
+                            ++ns;
+                        }
+                    } else {
+                        ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
+                    }
+                    sh.lw[p] += row[N];
+                    key = (cls - 1) * N + ns;
+                    c = part[ns * P + p];                        // sstar_id (:264)
+                    const int v = s.newid[key];
+                    sh.sid[p] = c;
+                    sh.kv[p] = v;
+                    sh.news[k * P + p] = (unsigned char)ns;
+                    s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
+                    fresh = v <= 0;
+                }
+                int cnt;
+                if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
+                if (wave_group(c, valid, cnt)) {
+                    bool won;
+                    const int slot = ht_insert(sh.h2, c, won, 48);
+                    if (slot < 0) sh.misc[M_OVF] = 1;
+                    else { atomicAdd(&sh.h2.a[slot], cnt); atomicMin(&sh.h2.b[slot], p); }
+                }
+            }
+            __syncthreads();
+            const bool gcensus = sh.misc[M_OVF] != 0;
+            PH(13);
+            if (gcensus) {   // too many distinct clusters for the LDS table: per-id tables in global memory
+                for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    const int c = valid ? sh.sid[p] : 0;
+                    int cnt;
+                    if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
+                }
+                __syncthreads();
+            }
+
+            // -- D: ranks in particle order: fresh class keys (:266-269) and distinct chosen
+            // clusters, clone-or-in-place (:276-299)
+            PH(6);
+            unsigned long long carry = 0;
+            for (int pb = 0; pb < P; pb += T) {
+                const int p = pb + tid;
+                const bool valid = p < P;
+                int key = 0, c = 0, slot = 0, ncp = 0;
+                bool fk = false, fc = false, nc = false;
+                if (valid) {
+                    c = sh.sid[p];
+                    if (sh.kv[p] <= 0) {
+                        key = (pidk[p] - 1) * N + sh.news[k * P + p];
+                        fk = s.newid[key] == p - P;
+                    }
+                    if (gcensus) { fc = s.firstc[c] == p; if (fc) ncp = s.ncop[c]; }
+                    else { slot = ht_find(sh.h2, c); fc = sh.h2.b[slot] == p; ncp = sh.h2.a[slot]; }
+                    nc = fc && (ncp != s.counts[c]);
+                }
+                unsigned long long tot;
+                const unsigned long long ex = block_flag_scan<T>(fk, fc, nc, tot, sh.scan) + carry;
+                if (fk) s.newid[key] = (int)(ex & 0xfffffull) + 1;
+                if (fc) {
+                    const int rc = (int)((ex >> 20) & 0xfffffull);
+                    const int tgt = nc ? maxid + (int)(ex >> 40) + 1 : c;
+                    if (tgt <= cap) {
+                        const int nnew = s.cn[c] + 1;
+                        if (nc) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }   // (:293-294)
+                        s.cn[tgt] = nnew;
+                        if (rc < a.dl_lds) {
+                            sh.dl[rc] = c; sh.dl[a.dl_lds + rc] = tgt; sh.dl[2 * a.dl_lds + rc] = nnew;
+                            sh.dl_slot[rc] = slot;
+                        } else {
+                            s.dl[rc] = c; s.dl[P + rc] = tgt; s.dl[2 * P + rc] = nnew;
+                        }
+                        if (gcensus) s.ncop[c] = tgt; else sh.h2.a[slot] = tgt;   // chosen id -> updated id
+                    }
+                }
+                carry += tot;
+            }
+            const int nd = (int)((carry >> 20) & 0xfffffull);
+            const int nclone = (int)(carry >> 40);
+            if (maxid + nclone > cap) failed = 1;
+            __syncthreads();
+            if (failed) break;
+
+            // -- E: apply: new class ids, remap cloned labels (:301-308)
+            PH(7);
+            for (int pb = 0; pb < P; pb += T) {
+                const int p = pb + tid;
+                const bool valid = p < P;
+                int newcls = 0;
+                if (valid) {
+                    const int ns = sh.news[k * P + p];
+                    const int key = (pidk[p] - 1) * N + ns;
+                    const int v = sh.kv[p];
+                    newcls = (v <= 0) ? s.newid[key] : v;
+                    const int c = sh.sid[p];
+                    const int tgt = gcensus ? s.ncop[c] : sh.h2.a[ht_find(sh.h2, c)];
+                    if (tgt != c) part[ns * P + p] = tgt;
+                    pidk[p] = newcls;
+                    sh.kv[p] = key;
+                }
+                int cnt;
+                if (wave_group(newcls, valid, cnt)) atomicMin(&sh.lead_of[newcls], p);
+            }
+            __syncthreads();
+
+            // -- F: class list for the next step; scratch clean-up; sufficient-statistic update
+            // of every distinct chosen cluster (deepcopy + cluster_add!, :297,:300):
+            // lanes = (cluster, feature)
+            PH(8);
+            {
+                unsigned long long ccarry = 0;
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    const int cls = valid ? pidk[p] : 0;
+                    const bool isl = valid && sh.lead_of[cls] == p;
+                    unsigned long long tot;
+                    const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, sh.scan) + ccarry;
+                    if (isl) { cl.set((int)ex, p, cls); sh.slot_of[cls] = (int)ex; }
+                    if (valid && a.q1 == 1) s.newid[sh.kv[p]] = 0;   // corrected mode: new_id per step
+                    ccarry += tot;
+                }
+                if (gcensus) {
+                    for (int j = tid; j < nd; j += T) {
+                        const int c = j < a.dl_lds ? sh.dl[j] : s.dl[j];
+                        s.ncop[c] = 0; s.firstc[c] = PMDI_INF_I;
+                    }
+                } else if (nd <= a.dl_lds) {
+                    for (int j = tid; j < nd; j += T) { const int sl = sh.dl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
+                } else {
+                    for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+                }
+                for (int it = tid; it < nd * D; it += T) {
+                    const int j = it / D, q = it - j * D;
+                    int src, dst, nnew;
+                    if (j < a.dl_lds) { src = sh.dl[j]; dst = sh.dl[a.dl_lds + j]; nnew = sh.dl[2 * a.dl_lds + j]; }
+                    else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
+                    const bool on = flk[q];
+                    if (d.kind == K_GAUSSIAN) {
+                        double2 ml = s.ml[(size_t)src * D + q], sb = s.sb[(size_t)src * D + q];
+                        if (on) gauss_add(sh.xs[q], nnew, ml, sb);
+                        if (on || dst != src) { s.ml[(size_t)dst * D + q] = ml; s.sb[(size_t)dst * D + q] = sb; }
+                    } else if (d.kind == K_CATEGORICAL) {
+                        const int x = ((const int *)sh.xs)[q];
+                        const int *cs = s.cnt + ((size_t)src * D + q) * d.L;
+                        int *cd = s.cnt + ((size_t)dst * D + q) * d.L;
+                        if (dst != src) for (int l = 0; l < d.L; ++l) cd[l] = cs[l];
+                        if (on) cd[x - 1] = cs[x - 1] + 1;
+                    } else {
+                        const int x = ((const int *)sh.xs)[q];
+                        s.nbs[(size_t)dst * D + q] = s.nbs[(size_t)src * D + q] + (on ? x : 0);
+                    }
+                }
+                st_nops += maxid;                     // src/__pmdi.jl:187
+                st_sumcls += ncls;
+                st_nclones += nclone;
+                if (maxid + nclone > st_maxid) st_maxid = maxid + nclone;
+                __syncthreads();
+                for (int r = tid; r < (int)ccarry; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
+                if (tid == 0) { sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = (int)ccarry; }
+            }
+            __syncthreads();
+        }
+        if (failed) break;
+
+        // -- Phi_upweight! (src/misc.jl:50-59)
+        PH(9);
+        if (K > 1) {
+            for (int p = tid; p < P; p += T) {
+                int pr = 0;
+                double w = sh.lw[p];
+                for (int k1 = 0; k1 < K - 1; ++k1)
+                    for (int k2 = k1 + 1; k2 < K; ++k2) {
+                        w += (sh.news[k1 * P + p] == sh.news[k2 * P + p]) ? logphi[pr] : 0.0;
+                        ++pr;
+                    }
+                sh.lw[p] = w;
+            }
+            lw_uniform = false;
+            __syncthreads();
+        }
+
+        // -- calc_ESS (src/misc.jl:15-25).  If every log-weight is the same number the sums are
+        // exact (P ones): ESS == P, no resampling; skip the exps.
+        if (!lw_uniform) {
+            const double l0 = sh.lw[0];
+            int same = 1;
+            for (int p = tid; p < P; p += T) same &= (sh.lw[p] == l0) ? 1 : 0;
+            lw_uniform = __syncthreads_and(same) != 0;
+        }
+        double ess = (double)P;
+        bool resample = false;
+        double mx = 0.0;
+        if (!lw_uniform) {
+            mx = -INFINITY;
+            for (int p = tid; p < P; p += T) { const double v = sh.lw[p]; mx = (v > mx) ? v : mx; }
+            mx = block_max<T>(mx, sh.red);
+            double sa = 0.0, sb2 = 0.0;
+            for (int p = tid; p < P; p += T) { const double w = exp(sh.lw[p] - mx); sa += w; sb2 += w * w; }
+            block_sum2<T>(sa, sb2, sh.red);
+            ess = (sa * sa) / sb2;
+            resample = ess <= 0.5 * (double)P;            // src/pmdi.jl:317
+        }
+
+        if (resample) {
+            // draw_partstar (src/misc.jl:27-47)
+            PH(10);
+            ++st_nres;
+            const double u01 = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
+            const double usl = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
+            double *wb = sh.term;
+            for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
+            __syncthreads();
+            if (tid == 0) jl_cumsum_inplace(wb, P);               // cumsum (:29), Julia's pairwise order
+            if (tid == T - 64) {                                  // u += 1/particles by repeated addition (:34)
+                double u = u01 / (double)P;
+                const double h = 1.0 / (double)P;
+                usc[0] = u;
+                for (int j = 1; j < P; ++j) { u += h; usc[j] = u; }
+            }
+            __syncthreads();
+            const double last = wb[P - 1];
+            for (int j = tid; j < P; j += T) {
+                const double uj = usc[j];
+                int lo = 0, hi = P - 1;           // smallest p with pprob[p]/last >= u_j
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (wb[mid] / last >= uj) hi = mid; else lo = mid + 1;
+                }
+                pstar_raw[j] = lo;
+            }
+            int js = (int)(usl * (double)P);      // shuffle!, partstar[1]=1, sort! (:43-45)
+            if (js >= P) js = P - 1;
+            for (int p = tid; p < P; p += T) sh.lw[p] = 1.0;     // src/pmdi.jl:319
+            lw_uniform = true;
+            __syncthreads();
+#define PMDI_ANC(pp) ((pp) == 0 ? 0 : ((pp) <= js ? pstar_raw[(pp) - 1] : pstar_raw[(pp)]))
+            for (int k = 0; k < K; ++k) {                         // src/pmdi.jl:320-340
+                const DsetDev &d = a.ds[k];
+                const KS s = make_ks(d, chain);
+                const int D = d.D;
+                const int cur = sh.kcur[k];
+                const int oldmax = sh.kmaxid[k];
+                int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
+                const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
+                const int *src = s.part[cur];
+                int *dst = s.part[cur ^ 1];
+                for (int idx = tid; idx < N * P; idx += T) {      // particle[:, partstar, k] (:322)
+                    const int nn = idx / P, p = idx - nn * P;
+                    const int v = src[nn * P + PMDI_ANC(p)];
+                    dst[idx] = v;
+                    s.ncop[v] = 1;                                // live-id marks
+                }
+                for (int p = tid; p < P; p += T) sh.sid[p] = pidk[PMDI_ANC(p)];   // (:323)
+                for (int id = 1 + tid; id <= oldmax; id += T) s.counts[id] = 0;   // (:326)
+                __syncthreads();
+                for (int p = tid; p < P; p += T) pidk[p] = sh.sid[p];
+                // sort(unique(particle)) ascending -> 1..U' (:329): scan of live marks
+                unsigned long long carry = 0;
+                for (int b = 0; b < oldmax; b += T) {
+                    const int id = 1 + b + tid;
+                    const bool live = (id <= oldmax) && s.ncop[id];
+                    unsigned long long tot;
+                    const unsigned long long ex = block_excl_scan<T>(live ? 1ull : 0ull, tot, sh.scan) + carry;
+                    if (live) s.firstc[id] = (int)ex + 1;
+                    carry += tot;
+                }
+                const int newmax = (int)carry;
+                __syncthreads();
+                for (int idx = tid; idx < N * P; idx += T) {      // relabel + recount (:331-338)
+                    const int v = s.firstc[dst[idx]];
+                    dst[idx] = v;
+                    atomicAdd(&s.counts[v], 1);
+                }
+                // clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending (:336):
+                // batches in ascending order, load -> barrier -> store
+                for (int b = 0; b < oldmax; b += T) {
+                    const int id = 1 + b + tid;
+                    const bool mv = (id <= oldmax) && s.ncop[id] && s.firstc[id] != id;
+                    const int v = mv ? s.cn[id] : 0;
+                    __syncthreads();
+                    if (mv) s.cn[s.firstc[id]] = v;
+                }
+                const long long nitems = (long long)oldmax * D;
+                if (d.kind == K_GAUSSIAN) {
+                    for (long long b = 0; b < nitems; b += T) {
+                        const long long it = b + tid;
+                        const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
+                        const bool mv = (it < nitems) && s.ncop[id] && s.firstc[id] != id;
+                        double2 ml = make_double2(0, 0), sb = make_double2(0, 0);
+                        if (mv) { ml = s.ml[(size_t)id * D + q]; sb = s.sb[(size_t)id * D + q]; }
+                        __syncthreads();
+                        if (mv) { const int nid = s.firstc[id]; s.ml[(size_t)nid * D + q] = ml; s.sb[(size_t)nid * D + q] = sb; }
+                    }
+                } else if (d.kind == K_CATEGORICAL) {
+                    const long long itemsL = nitems * d.L;
+                    const int DL = D * d.L;
+                    for (long long b = 0; b < itemsL; b += T) {
+                        const long long it = b + tid;
+                        const int id = 1 + (int)(it / DL), r = (int)(it - (long long)(id - 1) * DL);
+                        const bool mv = (it < itemsL) && s.ncop[id] && s.firstc[id] != id;
+                        const int v = mv ? s.cnt[(size_t)id * DL + r] : 0;
+                        __syncthreads();
+                        if (mv) s.cnt[(size_t)s.firstc[id] * DL + r] = v;
+                    }
+                } else {
+                    for (long long b = 0; b < nitems; b += T) {
+                        const long long it = b + tid;
+                        const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
+                        const bool mv = (it < nitems) && s.ncop[id] && s.firstc[id] != id;
+                        const long long v = mv ? s.nbs[(size_t)id * D + q] : 0;
+                        __syncthreads();
+                        if (mv) s.nbs[(size_t)s.firstc[id] * D + q] = v;
+                    }
+                }
+                __syncthreads();
+                for (int id = 1 + tid; id <= oldmax; id += T) { s.ncop[id] = 0; s.firstc[id] = PMDI_INF_I; }
+                __syncthreads();
+                const int nc2 = rebuild_classes<T>(pidk, cl, sh, P);
+                if (tid == 0) { sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1; }
+                __syncthreads();
+            }
+#undef PMDI_ANC
+        }
+
+        if (a.trace_on && tid == 0) {
+            double *tr = a.trace + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
+            tr[0] = ess;
+            tr[1] = resample ? 1.0 : 0.0;
+            for (int k = 0; k < K; ++k) { tr[2 + k] = (double)sh.kmaxid[k]; tr[2 + K + k] = (double)sh.kncls[k]; }
+        }
+    }
+
+    if (failed) {
+        if (tid == 0) a.err[chain] = -4;  // PMDI_E_POOL
+        return;
+    }
+
+    // ---- particle pick (src/pmdi.jl:345-350) + s = sstar[p_star,:,:] (:373) ----
+    PH(11);
+    {
+        double mx = -INFINITY;
+        for (int p = tid; p < P; p += T) { const double v = sh.lw[p]; mx = (v > mx) ? v : mx; }
+        mx = block_max<T>(mx, sh.red);
+        double *wb = sh.term;
+        for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
+        __syncthreads();
+        if (tid == 0) {   // StatsBase.sample(::Weights): sequential sum and scan, as the oracle
+            double sum = 0.0;
+            for (int p = 0; p < P; ++p) sum += wb[p];
+            const double t = uniform01(seed, iter, 0, 0, 0, SITE_PSTAR) * sum;
+            int ip = 0;
+            double cw = wb[0];
+            while (cw < t && ip < P - 1) { ++ip; cw += wb[ip]; }
+            sh.misc[M_PSTAR] = ip;
+        }
+        __syncthreads();
+        const int pstar = sh.misc[M_PSTAR];
+        for (long long pp = tid; pp < n; pp += T) {
+            const int i = order[pp];
+            for (int k = 0; k < K; ++k) {
+                int v;
+                if (pp < n1 - 1) v = s_in[(size_t)k * n + i];   // sstar[:, i, k] .= s[i, k] (:204)
+                else {
+                    const unsigned char *ss = (const unsigned char *)(a.ds[k].arena + (size_t)chain * a.ds[k].stride + a.ds[k].o_sstar);
+                    v = ss[(size_t)pp * P + pstar];
+                }
+                a.s_out[((size_t)chain * K + k) * n + i] = v;
+            }
+        }
+        if (a.lw_out) for (int p = tid; p < P; p += T) a.lw_out[(size_t)chain * P + p] = sh.lw[p];
+        if (a.pid_lds)   // debug export reads the class ids from global memory
+            for (int k = 0; k < K; ++k) {
+                int *gp = (int *)(a.ds[k].arena + (size_t)chain * a.ds[k].stride + a.ds[k].o_pid);
+                for (int p = tid; p < P; p += T) gp[p] = sh.pid[(size_t)k * P + p];
+            }
+        if (tid < K) {
+            a.kstate[((size_t)chain * PMDI_KMAX_I + tid) * 2] = sh.kmaxid[tid];
+            a.kstate[((size_t)chain * PMDI_KMAX_I + tid) * 2 + 1] = sh.kcur[tid];
+        }
+        PH(12);
+        if (a.phase && tid == 0) { sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0; }
+        __syncthreads();
+        if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
+        if (tid == 0) {
+            a.pstar[chain] = pstar;
+            long long *st = a.stats + (size_t)chain * 8;
+            st[ST_NOPS] = st_nops; st[ST_NRESAMPLE] = st_nres; st[ST_NCLONES] = st_nclones;
+            st[ST_MAXID] = st_maxid; st[ST_SUMCLASSES] = st_sumcls;
+            a.err[chain] = 0;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T)
+{
+    (void)T;
+    Carve c;
+    carve_lds(a, c);
+    return c.total;
+}
+
+hipError_t pmdi_launch_sweep(const SweepArgs &a, int n_chains, int T, hipStream_t stream)
+{
+    const size_t lds = pmdi_sweep_lds_bytes(a, T);
+    hipError_t e = hipSuccess;
+    if (T == 1024) {
+        e = hipFuncSetAttribute((const void *)pmdi_sweep_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(pmdi_sweep_kernel<1024>, dim3(n_chains), dim3(1024), lds, stream, a);
+    } else if (T == 512) {
+        e = hipFuncSetAttribute((const void *)pmdi_sweep_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(pmdi_sweep_kernel<512>, dim3(n_chains), dim3(512), lds, stream, a);
+    } else if (T == 256) {
+        e = hipFuncSetAttribute((const void *)pmdi_sweep_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(pmdi_sweep_kernel<256>, dim3(n_chains), dim3(256), lds, stream, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
