@@ -69,6 +69,7 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
         d.o_particle[1] = take((size_t)N * P * 4);
         d.o_pid = take((size_t)P * 4);
         d.o_sid = take((size_t)P * 4);
+        d.o_kv = take((size_t)P * 4);
         d.o_newid = take((size_t)N * P * 4);
         d.o_counts = take(ids * 4);
         d.o_ncop = take(ids * 4);
@@ -99,7 +100,7 @@ struct pmdi_handle {
     int T = 0;
     long long cap = 0;
     int Dmax = 0, sumD = 0, npairs = 1;
-    int terms_cap = 0, item_cap = 0, ht_size = 0, cls_lds = 0, dl_lds = 0, pid_lds = 0;
+    int terms_cap = 0, item_cap = 0, ht_size = 0, cls_lds = 0, dl_lds = 0, pid_lds = 0, pp_lds = 0;
     bool phase_on = false;
     hipStream_t stream = nullptr;
     DsetDev ds[PMDI_KMAX_I]{};
@@ -150,7 +151,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.Dmax = h->Dmax; a.sumD = h->sumD; a.npairs = h->npairs;
     a.q1 = h->cfg.q1_mode; a.q2 = h->cfg.q2_mode;
     a.terms_cap = h->terms_cap;
-    a.item_cap = h->item_cap; a.ht_size = h->ht_size; a.cls_lds = h->cls_lds; a.dl_lds = h->dl_lds; a.pid_lds = h->pid_lds;
+    a.item_cap = h->item_cap; a.ht_size = h->ht_size; a.cls_lds = h->cls_lds; a.dl_lds = h->dl_lds; a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
@@ -304,10 +305,14 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         h->item_cap = 512; h->ht_size = 1024; h->cls_lds = 256; h->dl_lds = 256;
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         SweepArgs a;
-        h->pid_lds = 1;
+        h->pid_lds = 1; h->pp_lds = 1;
         fill_sweep_common(h, a);
         if (pmdi_sweep_lds_bytes(a, h->T) > 150 * 1024) {      // class ids of K*P particles do not fit: keep them in global memory
             h->pid_lds = 0;
+            fill_sweep_common(h, a);
+        }
+        if (pmdi_sweep_lds_bytes(a, h->T) > 150 * 1024) {      // nor does the per-particle step scratch
+            h->pp_lds = 0;
             fill_sweep_common(h, a);
         }
         if (pmdi_sweep_lds_bytes(a, h->T) > 160 * 1024)

@@ -29,7 +29,7 @@ __device__ __forceinline__ double uniform01(unsigned long long seed, unsigned it
 // ---------------------------------------------------------------------------
 struct KS {  // pointers of one (chain, dataset)
     int *part[2];
-    int *pid, *sid, *newid, *counts, *ncop, *firstc, *cn, *clslead, *clsval, *dl;
+    int *pid, *sid, *kv, *newid, *counts, *ncop, *firstc, *cn, *clslead, *clsval, *dl;
     double *lp, *cdf;
     double2 *ml, *sb;
     int *cnt;
@@ -45,6 +45,7 @@ __device__ __forceinline__ KS make_ks(const DsetDev &d, int chain)
     s.part[1] = (int *)(b + d.o_particle[1]);
     s.pid = (int *)(b + d.o_pid);
     s.sid = (int *)(b + d.o_sid);
+    s.kv = (int *)(b + d.o_kv);
     s.newid = (int *)(b + d.o_newid);
     s.counts = (int *)(b + d.o_counts);
     s.ncop = (int *)(b + d.o_ncop);

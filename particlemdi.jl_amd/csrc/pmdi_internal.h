@@ -32,6 +32,7 @@ struct DsetDev {
     size_t o_particle[2];   // int  [N][P]  label -> cluster id (1-based), double buffered
     size_t o_pid;           // int  [P]     class of each particle (particle_id)
     size_t o_sid;           // int  [P]     sstar_id
+    size_t o_kv;            // int  [P]     per-particle scratch (class-key value), used when not in LDS
     size_t o_newid;         // int  [P][N]  new_id[(class-1)*N + label]
     size_t o_counts;        // int  [cap+1]
     size_t o_ncop;          // int  [cap+1] scratch, 0 between steps
@@ -58,6 +59,7 @@ struct SweepArgs {
     int cls_lds;            // class-list slots per dataset kept in LDS
     int dl_lds;             // distinct-chosen-cluster list entries kept in LDS
     int pid_lds;            // 1: particle class ids [K][P] live in LDS
+    int pp_lds;             // 1: per-particle step scratch (sid, kv) lives in LDS
     unsigned iter;
     long long n, n1;
     unsigned long long seed;

@@ -83,8 +83,8 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.scan = take(16 * 8);
     c.red = take(32 * 8);
     c.pid = take(a.pid_lds ? (size_t)a.K * a.P * 4 : 0);
-    c.sid = take((size_t)a.P * 4);
-    c.kv = take((size_t)a.P * 4);
+    c.sid = take(a.pp_lds ? (size_t)a.P * 4 : 0);
+    c.kv = take(a.pp_lds ? (size_t)a.P * 4 : 0);
     c.lead_of = take((size_t)(a.P + 1) * 4);
     c.slot_of = take((size_t)(a.P + 1) * 4);
     c.cl_lead = take((size_t)a.K * a.cls_lds * 4);
@@ -342,6 +342,8 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
             const int cur = sh.kcur[k];
             int *part = s.part[cur];
             int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
+            int *sidp = a.pp_lds ? sh.sid : s.sid;
+            int *kvp = a.pp_lds ? sh.kv : s.kv;
             const unsigned char *flk = sh.fl + (size_t)k * Dp;
             const double *pik = sh.pis + k * N;
             const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
@@ -538,8 +540,8 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                     key = (cls - 1) * N + ns;
                     c = part[ns * P + p];                        // sstar_id (:264)
                     const int v = s.newid[key];
-                    sh.sid[p] = c;
-                    sh.kv[p] = v;
+                    sidp[p] = c;
+                    kvp[p] = v;
                     sh.news[k * P + p] = (unsigned char)ns;
                     s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
                     fresh = v <= 0;
@@ -561,7 +563,7 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
                     const bool valid = p < P;
-                    const int c = valid ? sh.sid[p] : 0;
+                    const int c = valid ? sidp[p] : 0;
                     int cnt;
                     if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
                 }
@@ -578,8 +580,8 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                 int key = 0, c = 0, slot = 0, ncp = 0;
                 bool fk = false, fc = false, nc = false;
                 if (valid) {
-                    c = sh.sid[p];
-                    if (sh.kv[p] <= 0) {
+                    c = sidp[p];
+                    if (kvp[p] <= 0) {
                         key = (pidk[p] - 1) * N + sh.news[k * P + p];
                         fk = s.newid[key] == p - P;
                     }
@@ -623,13 +625,13 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                 if (valid) {
                     const int ns = sh.news[k * P + p];
                     const int key = (pidk[p] - 1) * N + ns;
-                    const int v = sh.kv[p];
+                    const int v = kvp[p];
                     newcls = (v <= 0) ? s.newid[key] : v;
-                    const int c = sh.sid[p];
+                    const int c = sidp[p];
                     const int tgt = gcensus ? s.ncop[c] : sh.h2.a[ht_find(sh.h2, c)];
                     if (tgt != c) part[ns * P + p] = tgt;
                     pidk[p] = newcls;
-                    sh.kv[p] = key;
+                    kvp[p] = key;
                 }
                 int cnt;
                 if (wave_group(newcls, valid, cnt)) atomicMin(&sh.lead_of[newcls], p);
@@ -650,7 +652,7 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                     unsigned long long tot;
                     const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, sh.scan) + ccarry;
                     if (isl) { cl.set((int)ex, p, cls); sh.slot_of[cls] = (int)ex; }
-                    if (valid && a.q1 == 1) s.newid[sh.kv[p]] = 0;   // corrected mode: new_id per step
+                    if (valid && a.q1 == 1) s.newid[kvp[p]] = 0;   // corrected mode: new_id per step
                     ccarry += tot;
                 }
                 if (gcensus) {
@@ -775,6 +777,7 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                 const int cur = sh.kcur[k];
                 const int oldmax = sh.kmaxid[k];
                 int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
+                int *sidp = a.pp_lds ? sh.sid : s.sid;
                 const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
                 const int *src = s.part[cur];
                 int *dst = s.part[cur ^ 1];
@@ -784,10 +787,10 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                     dst[idx] = v;
                     s.ncop[v] = 1;                                // live-id marks
                 }
-                for (int p = tid; p < P; p += T) sh.sid[p] = pidk[PMDI_ANC(p)];   // (:323)
+                for (int p = tid; p < P; p += T) sidp[p] = pidk[PMDI_ANC(p)];   // (:323)
                 for (int id = 1 + tid; id <= oldmax; id += T) s.counts[id] = 0;   // (:326)
                 __syncthreads();
-                for (int p = tid; p < P; p += T) pidk[p] = sh.sid[p];
+                for (int p = tid; p < P; p += T) pidk[p] = sidp[p];
                 // sort(unique(particle)) ascending -> 1..U' (:329): scan of live marks
                 unsigned long long carry = 0;
                 for (int b = 0; b < oldmax; b += T) {

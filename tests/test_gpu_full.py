@@ -1,0 +1,95 @@
+"""Full-size checks (BASELINE.json configs[1]: 10k x 50 Gaussian, N=20, 1024 particles): one
+iteration compared with the oracle end to end, then size-independent properties over a batch of
+chains: determinism, label range, the T5 pool/count invariants, known prefix kept.
+Also the pmdi() driver on the README-sized problem, and feature selection at moderate size."""
+import numpy as np
+import pytest
+
+from _cases import t5_invariants
+from conftest import random_hypers
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg2_full_size(pkg, O):
+    from particlemdi_jl_amd import workloads
+    w = workloads.make("cfg2")
+    n, N, P = w["n"], w["N"], w["P"]
+    assert (n, N, P, w["D"]) == (10000, 20, 1024, [50])
+    rng = np.random.default_rng(0)
+    # a plausible mid-chain state: the true clustering with 3% of labels scrambled
+    s = (w["truth"] + 1).reshape(n, 1).copy()
+    idx = rng.random(n) < 0.03
+    s[idx, 0] = rng.integers(1, N + 1, size=idx.sum())
+    order = rng.permutation(n) + 1
+    Pi, Phi = random_hypers(rng, N, 1)
+    Pi[:3, 0] += 1.0; Pi /= Pi.sum(0)
+    n1 = n // 4
+    sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=3, seed=500)
+    S = np.repeat(s[None], 3, 0); Ord = np.repeat(order[None], 3, 0)
+    PiC = np.repeat(Pi[None], 3, 0); PhiC = np.repeat(Phi[None], 3, 0)
+    r1 = sw.sweep(2, S, Ord, n1, PiC, PhiC)
+    # oracle, chain 0, same inputs: allocations exact, log-weights within the stated tolerance
+    o = O.Oracle(w["data"], w["kinds"], N, P, seed=500).sweep(2, s, order, n1, Pi, Phi)
+    assert (r1["s"][0] == o["s"]).all() and int(r1["p_star"][0]) == o["p_star"]
+    assert np.allclose(r1["logweight"][0], o["logweight"], rtol=1e-6)        # north_star tolerance
+    assert r1["stats"][0]["n_operations"] == o["stats"]["n_operations"]
+    # size-independent properties
+    r2 = sw.sweep(2, S, Ord, n1, PiC, PhiC)
+    assert (r1["s"] == r2["s"]).all() and (r1["p_star"] == r2["p_star"]).all()          # determinism
+    assert r1["s"].min() >= 1 and r1["s"].max() <= N
+    pre = order[:n1 - 1] - 1
+    assert (r1["s"][:, pre, :] == S[:, pre, :]).all()                                    # known prefix kept
+    assert (r1["s"][1] != r1["s"][0]).any() or (r1["s"][2] != r1["s"][0]).any()         # chains use seed + c
+    for c in range(3):
+        t5_invariants(sw.export_state(c), N, P, 1, n)
+    # the sweep recovers the planted clustering up to label names (adjusted agreement)
+    from collections import Counter
+    pairs = Counter(zip(w["truth"].tolist(), r1["s"][0][:, 0].tolist()))
+    agree = sum(max(v for (t, _), v in pairs.items() if t == tt) for tt in range(3))
+    assert agree > 0.97 * n
+
+
+def test_feature_selection_matches_oracle(pkg, O):
+    from particlemdi_jl_amd import workloads
+    w = workloads.make("cfg4", 0.03)          # 2 x Gaussian, Categorical, NegBinom; 300 obs
+    n, K = w["n"], w["K"]
+    N, P = 12, 64
+    rng = np.random.default_rng(1)
+    traj = np.stack([(w["truth"] + 1 + k) % 5 + 1 for k in range(K)], axis=1)
+    sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=2, seed=31)
+    fl, pr = sw.feature_select(4, np.stack([traj, traj[::-1].copy()]))
+    for c, tr in enumerate((traj, traj[::-1].copy())):
+        of, op = O.Oracle(w["data"], w["kinds"], N, P, seed=31 + c).feature_select(4, tr)
+        off = 0
+        for k in range(K):
+            D = w["D"][k]
+            if w["kinds"][k] == "gaussian":
+                assert np.allclose(pr[c, off:off + D], op[k], rtol=1e-10)
+            else:
+                assert (pr[c, off:off + D] == op[k]).all()           # integer statistics: bit-exact
+            assert (fl[c, off:off + D] == of[k]).all()
+            off += D
+
+
+def test_pmdi_driver_csv(pkg, tmp_path):
+    from particlemdi_jl_amd import workloads
+    from particlemdi_jl_amd.pmdi import pmdi
+    w = workloads.make("cfg1")                # the README example's shape: 150 x 4, N=10, 32 particles
+    out = tmp_path / "out.csv"
+    fs = tmp_path / "fs.csv"
+    st = pmdi(w["data"], ["GaussianCluster"], 10, 32, 0.25, 30, str(out), thin=2, featureSelect=str(fs),
+              seed=3, return_state=True)
+    lines = out.read_text().strip().split("\n")
+    header = lines[0].split(",")
+    assert header[:3] == ["MassParameter_1", "phi_1_1", "ll"] and header[3] == "K1_n1" and len(header) == 3 + 150
+    assert len(lines) == 1 + 1 + 15                       # header, initial row, every 2nd iteration
+    rows = np.array([[float(v) for v in ln.split(",")] for ln in lines[1:]])
+    assert (np.diff(rows[:, 2]) > 0).all()                # ll = cumulative seconds (src/pmdi.jl:377)
+    assert rows[:, 3:].min() >= 1 and rows[:, 3:].max() <= 10
+    assert len(fs.read_text().strip().split("\n")) == 1 + 1 + 15
+    assert st["s"].shape == (150, 1)
+    # three well separated components are found again
+    from collections import Counter
+    top = Counter(st["s"][:, 0].tolist()).most_common(3)
+    assert sum(v for _, v in top) > 120

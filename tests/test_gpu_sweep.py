@@ -1,0 +1,171 @@
+"""Parity of the HIP sweep (through the C ABI) with the oracle: golden vectors, seeded random
+cases, the reference's T5 invariants on the exported device state, edge cases, batched chains,
+and the device-pointer entry point."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _cases import golden_cases, load_golden, replay, t5_invariants
+from conftest import make_mixed, random_hypers
+
+pytestmark = pytest.mark.gpu
+
+
+class GpuRunner:
+    def __init__(self, pkg, data, kinds, N, P, seed, q1, **kw):
+        self.sw = pkg.Sweeper(data, kinds, N, P, n_chains=1, seed=seed, q1_mode=q1, **kw)
+
+    def sweep(self, it, s, order, n1, Pi, Phi, flags, trace=False):
+        r = self.sw.sweep(it, s[None], order[None], n1, Pi[None], np.atleast_1d(Phi)[None],
+                          flags=None if flags is None else flags[None], trace=trace)
+        out = {"s": r["s"][0], "p_star": int(r["p_star"][0]), "logweight": r["logweight"][0], "stats": r["stats"][0]}
+        if trace:
+            out["trace"] = r["trace"][0]
+        return out
+
+    def feature_select(self, it, s):
+        f, p = self.sw.feature_select(it, s[None])
+        return f[0], p[0]
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_golden(pkg, case):
+    z, data, kinds = load_golden(case)
+    replay(z, data, kinds, lambda d, k, N, P, seed, q1: GpuRunner(pkg, d, k, N, P, seed, q1))
+
+
+def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, block=0, check_state=True):
+    rng = np.random.default_rng(seed)
+    n, K = data[0].shape[0], len(data)
+    g = GpuRunner(pkg, data, kinds, N, P, seed, q1, block_threads=block)
+    o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1)
+    Dcum = np.cumsum([d.shape[1] for d in data])[:-1]
+    s = rng.integers(1, N + 1, size=(n, K))
+    for it in range(1, iters + 1):
+        order = rng.permutation(n) + 1
+        Pi, Phi = random_hypers(rng, N, K)
+        rg = g.sweep(it, s, order, n1, Pi, Phi, flags, trace=True)
+        ro = o.sweep(it, s, order, n1, Pi, Phi, flags=None if flags is None else np.split(flags, Dcum), trace=True)
+        bad = np.where(~np.isclose(rg["trace"], ro["trace"], rtol=1e-9, atol=1e-9).all(axis=1))[0]
+        assert bad.size == 0, f"first diverging swept observation: {bad[0]} gpu={rg['trace'][bad[0]]} cpu={ro['trace'][bad[0]]}"
+        assert (rg["s"] == ro["s"]).all()
+        assert rg["p_star"] == ro["p_star"]
+        assert np.allclose(rg["logweight"], ro["logweight"], rtol=1e-9, atol=1e-8)
+        for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
+            assert rg["stats"][key] == ro["stats"][key], key
+        s = ro["s"]
+    if check_state:
+        eg, eo = g.sw.export_state(0), o.export()
+        for key in ("particle", "counts", "cluster_n", "max_id"):
+            assert (eg[key] == eo[key]).all(), key
+        t5_invariants(eg, N, P, K, n)
+    return g
+
+
+@pytest.mark.parametrize("P,iters,block", [(2, 2, 0), (64, 3, 0), (1024, 3, 0), (1024, 2, 256), (1024, 2, 1024), (300, 2, 0)])
+def test_T5_problem(pkg, O, P, iters, block):
+    # the reference's integration problem: test/runtests.jl:136-162
+    rng = np.random.default_rng(0)
+    data = [np.vstack([rng.normal(2, 1, (50, 16)), rng.normal(-2, 1, (50, 16))]) for _ in range(3)]
+    _compare_run(pkg, O, data, ["gaussian"] * 3, 10, P, iters, 40 + P, 25, block=block)
+
+
+@pytest.mark.parametrize("q1", [0, 1])
+def test_mixed_types(pkg, O, q1):
+    rng = np.random.default_rng(1)
+    data, kinds = make_mixed(rng, 300)
+    _compare_run(pkg, O, data, kinds, 12, 256, 3, 50 + q1, 75, q1=q1)
+
+
+def test_feature_flags(pkg, O):
+    rng = np.random.default_rng(2)
+    data, kinds = make_mixed(rng, 200)
+    fl = (rng.random(8 + 6 + 5) < 0.6).astype(np.uint8)
+    _compare_run(pkg, O, data, kinds, 12, 200, 2, 60, 50, flags=fl)
+    fl0 = np.zeros(8 + 6 + 5, dtype=np.uint8)       # every feature off: only the prior Pi drives the draws
+    _compare_run(pkg, O, data, kinds, 6, 64, 1, 61, 50, flags=fl0)
+
+
+@pytest.mark.parametrize("N,P,n1,n", [(2, 2, 1, 40), (2, 33, 40, 40), (10, 17, 2, 60), (64, 128, 16, 130), (5, 4096, 10, 50)])
+def test_edges(pkg, O, N, P, n1, n):
+    # n1 = 1: no known prefix; n1 = n: a single swept observation; N = 2 / N = 64: label-count limits;
+    # P not a multiple of the wave size; P = 4096: four particles per lane
+    rng = np.random.default_rng(N * 1000 + P)
+    z = rng.integers(0, 2, n)
+    g = rng.normal(size=(n, 3)) + 3.0 * z[:, None]
+    c = 1 + z[:, None] * np.ones((1, 2), dtype=np.int64) + rng.integers(0, 2, (n, 2))
+    _compare_run(pkg, O, [g, c], ["gaussian", "categorical"], N, P, 2, 70 + N, n1)
+
+
+def test_chains_are_independent_and_seeded(pkg, O):
+    rng = np.random.default_rng(3)
+    data, kinds = make_mixed(rng, 150)
+    N, P, K, n, Cn = 8, 128, 3, 150, 5
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=Cn, seed=900)
+    s = rng.integers(1, N + 1, size=(Cn, n, K))
+    order = np.stack([rng.permutation(n) + 1 for _ in range(Cn)])
+    hyp = [random_hypers(rng, N, K) for _ in range(Cn)]
+    r = sw.sweep(1, s, order, 37, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]))
+    for c in range(Cn):          # chain c == a single-chain oracle run with seed + c
+        o = O.Oracle(data, kinds, N, P, seed=900 + c).sweep(1, s[c], order[c], 37, hyp[c][0], hyp[c][1])
+        assert (r["s"][c] == o["s"]).all() and int(r["p_star"][c]) == o["p_star"]
+        assert r["stats"][c]["n_operations"] == o["stats"]["n_operations"]
+
+
+def test_pool_overflow_is_reported(pkg):
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(200, 4))                     # no structure: particles diverge, the pool grows
+    N, P = 10, 256
+    sw = pkg.Sweeper([x], ["gaussian"], N, P, pool_cap=N + 4)
+    Pi, Phi = random_hypers(rng, N, 1)
+    with pytest.raises(pkg.PmdiError) as e:
+        sw.sweep(1, rng.integers(1, N + 1, size=(1, 200, 1)), (rng.permutation(200) + 1)[None], 50, Pi[None], Phi[None])
+    assert e.value.code == -4                         # PMDI_E_POOL
+
+
+def test_bad_arguments(pkg):
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(50, 2))
+    sw = pkg.Sweeper([x], ["gaussian"], 4, 8)
+    Pi, Phi = random_hypers(rng, 4, 1)
+    s = rng.integers(1, 5, size=(1, 50, 1))
+    order = (rng.permutation(50) + 1)[None]
+    with pytest.raises(pkg.PmdiError) as e:
+        sw.sweep(1, s, order, 0, Pi[None], Phi[None])            # rho*n < 1
+    assert e.value.code == -1
+    with pytest.raises(pkg.PmdiError) as e:
+        sw.sweep(1, s * 0 + 5, order, 10, Pi[None], Phi[None])   # label outside 1..N
+    assert e.value.code == -5
+    with pytest.raises(pkg.PmdiError):
+        pkg.Sweeper([np.zeros((10, 2), dtype=np.int64)], ["categorical"], 3, 4)   # level < 1
+
+
+def test_device_pointer_entry_matches_host_entry(pkg, O):
+    import torch
+    from particlemdi_jl_amd._lib import _check, lib
+    rng = np.random.default_rng(6)
+    data, kinds = make_mixed(rng, 120)
+    N, P, K, n, n1 = 7, 64, 3, 120, 30
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=1, seed=77)
+    s = rng.integers(1, N + 1, size=(n, K))
+    order = rng.permutation(n) + 1
+    Pi, Phi = random_hypers(rng, N, K)
+    want = O.Oracle(data, kinds, N, P, seed=77).sweep(1, s, order, n1, Pi, Phi)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+    s_d = t((s.T - 1)[None], torch.int32); o_d = t((order - 1)[None], torch.int32)
+    Pi_d = t(Pi.T[None], torch.float64); lp_d = t(np.log(1.0 + Phi)[None], torch.float64)
+    so = torch.empty_like(s_d); lw = torch.empty((1, P), dtype=torch.float64, device=dev)
+    ps = torch.empty(1, dtype=torch.int32, device=dev); st = torch.zeros((1, 8), dtype=torch.int64, device=dev)
+    er = torch.ones(1, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    _check(lib().pmdi_sweep_device(sw.h, 1, C.c_void_p(s_d.data_ptr()), C.c_void_p(o_d.data_ptr()), n1,
+                                   C.c_void_p(Pi_d.data_ptr()), C.c_void_p(lp_d.data_ptr()), None, 0.0,
+                                   C.c_void_p(so.data_ptr()), C.c_void_p(lw.data_ptr()), C.c_void_p(ps.data_ptr()),
+                                   C.c_void_p(st.data_ptr()), C.c_void_p(er.data_ptr()), C.c_void_p(stream.cuda_stream)))
+    torch.cuda.synchronize()
+    assert int(er.item()) == 0
+    assert (so.cpu().numpy()[0].T + 1 == want["s"]).all()
+    assert int(ps.item()) + 1 == want["p_star"]
+    assert int(st[0, 0].item()) == want["stats"]["n_operations"]

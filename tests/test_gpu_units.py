@@ -1,0 +1,107 @@
+"""Device plugin protocol (calc_logprob / cluster_add! / calc_logmarginal through the C ABI)
+against the oracle.  Tolerances: integer statistics bit-exact; Gaussian floating point within
+1e-6 relative (north_star) -- in practice ~1e-15, asserted at 1e-12."""
+import numpy as np
+import pytest
+from scipy import stats
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-12       # << the 1e-6 relative the north_star allows for Gaussian log-predictives
+
+
+@pytest.fixture(scope="module")
+def mixed(pkg):
+    from conftest import make_mixed
+    rng = np.random.default_rng(21)
+    data, kinds = make_mixed(rng, 240)
+    sw = pkg.Sweeper(data, kinds, 8, 32, n_chains=1, seed=1)
+    yield data, kinds, sw
+    sw.close()
+
+
+def test_T1_gaussian_on_device(pkg):
+    rng = np.random.default_rng(10)
+    n = 1000
+    x = rng.normal(size=(n, 1))
+    sw = pkg.Sweeper([x], ["gaussian"], 4, 8)
+    cb = sw.clusters(0, 1)
+    for i in range(n):
+        cb.add([i + 1])
+    st = cb.stats()[0]
+    nn, mu, Sig, lam, beta = st[0], st[1], st[2], st[3], st[4]
+    assert nn == n and np.isclose(Sig, x.sum()) and np.isclose(mu, Sig / (n + 0.001))
+    xbar = Sig / n
+    s2 = ((x - xbar) ** 2).sum()
+    assert np.isclose(beta, 0.5 + 0.5 * (s2 + (0.001 * n * xbar ** 2) / (n + 0.001)))
+    assert np.isclose(lam, ((0.5 + n * 0.5) * (n + 0.001)) / (beta * (n + 1.001)))
+    xc = (x[-1, 0] - mu) * np.sqrt(lam)
+    assert np.isclose(stats.t.logpdf(xc, n + 1) + 0.5 * np.log(lam), cb.logprob([n])[0], rtol=1.5e-8)
+
+
+def test_T2_categorical_on_device(pkg):
+    rng = np.random.default_rng(11)
+    x = rng.integers(1, 11, size=(1000, 1))
+    x[0, 0] = 10
+    sw = pkg.Sweeper([x], ["categorical"], 4, 8)
+    cb = sw.clusters(0, 1)
+    for i in range(1000):
+        cb.add([i + 1])
+    st = cb.stats()[0]
+    assert st[0] == 1000
+    for lvl in np.unique(x):
+        assert (x == lvl).sum() == st[1 + lvl - 1]
+    row1 = int(np.where(x[:, 0] == 1)[0][0]) + 1
+    assert np.isclose(cb.logprob([row1])[0], np.log(((x == 1).sum() + 0.5) / 1005))
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+@pytest.mark.parametrize("use_flags", [False, True])
+def test_batch_matches_oracle(O, mixed, k, use_flags):
+    data, kinds, sw = mixed
+    rng = np.random.default_rng(30 + k)
+    B, n, D = 16, data[k].shape[0], data[k].shape[1]
+    flag = (rng.random(D) < 0.6).astype(np.uint8) if use_flags else None
+    cb = sw.clusters(k, B)
+    oc = [O.Cluster(data[k], kinds[k]) for _ in range(B)]
+    for step in range(25):
+        rows = rng.integers(0, n, size=B)
+        cb.add(rows + 1, flag)
+        for b in range(B):
+            oc[b].add(int(rows[b]), flag)
+    probe = rng.integers(0, n, size=B)
+    got = cb.logprob(probe + 1, flag)
+    want = np.array([oc[b].logprob(int(probe[b]), flag) for b in range(B)])
+    lm_got = cb.logmarginal()
+    lm_want = np.stack([oc[b].logmarginal() for b in range(B)])
+    if kinds[k] == "gaussian":
+        assert np.allclose(got, want, rtol=RTOL, atol=0)
+        assert np.allclose(lm_got, lm_want, rtol=RTOL, atol=0)
+    else:   # integer statistics + host-built tables: bit-exact
+        assert (got == want).all()
+        assert (lm_got == lm_want).all()
+    st = cb.stats()
+    for b in range(B):
+        o = oc[b].stats()
+        assert st[b, 0] == o["n"]
+        if kinds[k] == "gaussian":
+            assert (st[b, 1:1 + D] == o["mu"]).all() and (st[b, 1 + D:1 + 2 * D] == o["Sigma"]).all()
+            assert (st[b, 1 + 2 * D:1 + 3 * D] == o["lambda"]).all() and (st[b, 1 + 3 * D:1 + 4 * D] == o["beta"]).all()
+        elif kinds[k] == "categorical":
+            L = int(data[k].max())
+            assert (st[b, 1:].reshape(D, L).T == o["counts"]).all()
+        else:
+            assert (st[b, 1:] == o["Sigma"]).all()
+
+
+def test_empty_cluster_is_prior_predictive(O, mixed):
+    data, kinds, sw = mixed
+    for k in range(3):
+        cb = sw.clusters(k, 4)
+        rows = np.array([1, 2, 3, 4])
+        got = cb.logprob(rows)
+        want = np.array([O.Cluster(data[k], kinds[k]).logprob(int(r - 1)) for r in rows])
+        if kinds[k] == "gaussian":
+            assert np.allclose(got, want, rtol=RTOL)
+        else:
+            assert (got == want).all()
