@@ -57,11 +57,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--chains", type=int, default=256, help="independent chains per GPU (one workgroup each)")
+    ap.add_argument("--chains", type=int, default=1024, help="independent chains per GPU (one workgroup each)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n of the workload (debug only)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=30)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +133,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2: 3-mixture Gaussian 10000x50, K=1, N=20, P=1024, rho=0.25"
                        if args.scale == 1.0 else f"cfg2 scaled n={n}",
-                       "chains_per_gpu": C, "block_threads": g.sw.P and (args.block or 1024),
+                       "chains_per_gpu": C, "block_threads": g.sw.block_threads, "lds_bytes_per_chain": g.sw.lds_bytes,
                        "swept_obs_per_iter": n_s, "parallelism": f"chains x{world}"},
             "obs_particles_per_sec": total_iters * n_s * P / dt,
             "per_chain_iters_per_sec": 1e3 / kernel_ms,

@@ -175,6 +175,8 @@ int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);
 
 /* sizes a caller needs to allocate outputs */
 int pmdi_sum_D(const pmdi_handle *h);
+int pmdi_block_threads(const pmdi_handle *h);   /* threads per chain workgroup */
+int64_t pmdi_lds_bytes(const pmdi_handle *h);    /* LDS bytes per chain workgroup */
 int64_t pmdi_pool_cap(const pmdi_handle *h);
 int pmdi_categorical_L(const pmdi_handle *h, int32_t k);
 

@@ -28,6 +28,7 @@ EXPORTS = [
     "pmdi_sweep_device", "pmdi_feature_select", "pmdi_export_state", "pmdi_clusters_new",
     "pmdi_clusters_free", "pmdi_cluster_add", "pmdi_calc_logprob", "pmdi_calc_logmarginal",
     "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L", "pmdi_phase_timers",
+    "pmdi_block_threads", "pmdi_lds_bytes",
 ]
 
 
@@ -121,6 +122,10 @@ def lib():
     L.pmdi_pool_cap.argtypes = [vp]
     L.pmdi_categorical_L.restype = C.c_int
     L.pmdi_categorical_L.argtypes = [vp, i32]
+    L.pmdi_block_threads.restype = C.c_int
+    L.pmdi_block_threads.argtypes = [vp]
+    L.pmdi_lds_bytes.restype = i64
+    L.pmdi_lds_bytes.argtypes = [vp]
     L.pmdi_phase_timers.restype = C.c_int
     L.pmdi_phase_timers.argtypes = [vp, i32, vp]
     _lib = L
@@ -173,6 +178,8 @@ class Sweeper:
         self.h = h
         self.sumD = L.pmdi_sum_D(h)
         self.cap = L.pmdi_pool_cap(h)
+        self.block_threads = L.pmdi_block_threads(h)
+        self.lds_bytes = L.pmdi_lds_bytes(h)
         self.npairs = max(1, self.K * (self.K - 1) // 2)
         self._keep = None  # the library copied the data
 

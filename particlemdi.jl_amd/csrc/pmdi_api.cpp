@@ -298,11 +298,17 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if (h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 256, 512 or 1024"));
     {
         // LDS term buffer: at least P doubles (resampling weights) and a few rows of 2*D+1
-        int tc = 2048;
-        if (tc < P) tc = P;
+        auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+        int tc = env_int("PMDI_TERMS_CAP", 1024);
+        if (tc < P) tc = P;                                   // resampling weights
+        if (tc < (h->T / 64) * 128) tc = (h->T / 64) * 128;   // per-wave CDF exchange areas
         if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
         h->terms_cap = tc;
-        h->item_cap = 512; h->ht_size = 1024; h->cls_lds = 256; h->dl_lds = 256;
+        h->item_cap = env_int("PMDI_ITEM_CAP", 256);
+        h->ht_size = env_int("PMDI_HT_SIZE", 512);
+        if (h->item_cap < 2 * N) h->item_cap = 2 * N;
+        while (h->ht_size < 2 * h->item_cap || (h->ht_size & (h->ht_size - 1))) h->ht_size = (h->ht_size | (h->ht_size - 1)) + 1;
+        h->cls_lds = h->item_cap / 2; h->dl_lds = env_int("PMDI_DL_LDS", 128);
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         SweepArgs a;
         h->pid_lds = 1; h->pp_lds = 1;
@@ -363,6 +369,14 @@ int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16)
     return PMDI_OK;
 }
 
+int pmdi_block_threads(const pmdi_handle *h) { return h ? h->T : 0; }
+int64_t pmdi_lds_bytes(const pmdi_handle *h)
+{
+    if (!h) return 0;
+    SweepArgs a;
+    fill_sweep_common(h, a);
+    return (int64_t)pmdi_sweep_lds_bytes(a, h->T);
+}
 int pmdi_sum_D(const pmdi_handle *h) { return h ? h->sumD : 0; }
 int64_t pmdi_pool_cap(const pmdi_handle *h) { return h ? h->cap : 0; }
 int pmdi_categorical_L(const pmdi_handle *h, int32_t k) { return (h && k >= 0 && k < h->cfg.K) ? h->ds[k].L : 0; }
