@@ -83,7 +83,7 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
     }
     d.o_cn = take(ids * 4);
     if (d.kind == K_GAUSSIAN) {
-        d.o_ml = take(ids * d.D * 16);
+        if (!sweep_state) d.o_ml = take(ids * d.D * 16);   // stand-alone batches keep (mu, lambda) as stored values
         d.o_sb = take(ids * d.D * 16);
     } else if (d.kind == K_CATEGORICAL) {
         d.o_cnt = take(ids * d.D * d.L * 4);
@@ -100,7 +100,7 @@ struct pmdi_handle {
     int T = 0;
     long long cap = 0;
     int Dmax = 0, sumD = 0, npairs = 1;
-    int terms_cap = 0, item_cap = 0, ht_size = 0, cls_lds = 0, dl_lds = 0, pid_lds = 0, pp_lds = 0;
+    int terms_cap = 0, item_cap = 0, ht_size = 0, cls_lds = 0, dl_lds = 0, pid_lds = 0, pp_lds = 0, two_per_cu = 0;
     bool phase_on = false;
     hipStream_t stream = nullptr;
     DsetDev ds[PMDI_KMAX_I]{};
@@ -151,7 +151,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.Dmax = h->Dmax; a.sumD = h->sumD; a.npairs = h->npairs;
     a.q1 = h->cfg.q1_mode; a.q2 = h->cfg.q2_mode;
     a.terms_cap = h->terms_cap;
-    a.item_cap = h->item_cap; a.ht_size = h->ht_size; a.cls_lds = h->cls_lds; a.dl_lds = h->dl_lds; a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds;
+    a.item_cap = h->item_cap; a.ht_size = h->ht_size; a.cls_lds = h->cls_lds; a.dl_lds = h->dl_lds; a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
@@ -308,6 +308,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         h->ht_size = env_int("PMDI_HT_SIZE", 512);
         if (h->item_cap < 2 * N) h->item_cap = 2 * N;
         while (h->ht_size < 2 * h->item_cap || (h->ht_size & (h->ht_size - 1))) h->ht_size = (h->ht_size | (h->ht_size - 1)) + 1;
+        h->two_per_cu = env_int("PMDI_TWO_PER_CU", 0);
         h->cls_lds = h->item_cap / 2; h->dl_lds = env_int("PMDI_DL_LDS", 128);
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         SweepArgs a;

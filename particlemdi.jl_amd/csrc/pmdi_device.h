@@ -230,6 +230,27 @@ __device__ __forceinline__ void gauss_add(double x, int nnew, double2 &ml, doubl
     ml.y = ((0.5 * n + 0.5) * (n + 0.001)) / (sb.y * (n + 1.001));
 }
 
+// The sweep's pool stores only (Sigma, beta) per feature: mu and lambda are pure functions of
+// (Sigma, beta, n) -- gaussian_cluster.jl:60-63 recomputes them from exactly these values at
+// every add -- so they are derived on demand, bit-identically, and an update touches 16 bytes
+// instead of 64.  (Valid while the feature flags are fixed for the lifetime of the pool, which
+// holds inside a sweep: a feature is either updated at every add or never read.)
+__device__ __forceinline__ void gauss_add_sb(double x, int nnew, double2 &sb)
+{
+    const double n = (double)nnew;
+    const double mu_prev = (nnew == 1) ? 0.0 : sb.x / ((double)(nnew - 1) + 0.001);
+    sb.x = sb.x + x;
+    const double d = x - mu_prev;
+    sb.y = sb.y + ((double)(nnew - 1) + 0.001) * (d * d) / (2.0 * (n + 0.001));
+}
+
+__device__ __forceinline__ double2 gauss_ml(int cn, double2 sb)
+{
+    if (cn == 0) return make_double2(0.0, 1.0);          // GaussianCluster(dataFile): mu = 0, lambda = 1
+    const double n = (double)cn;
+    return make_double2(sb.x / (n + 0.001), ((0.5 * n + 0.5) * (n + 0.001)) / (sb.y * (n + 1.001)));
+}
+
 // the two per-feature terms of calc_logprob(::GaussianCluster): gaussian_cluster.jl:45-48
 __device__ __forceinline__ void gauss_terms(double x, double n, double2 ml, double &ta, double &tb)
 {

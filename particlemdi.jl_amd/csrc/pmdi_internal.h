@@ -39,7 +39,7 @@ struct DsetDev {
     size_t o_firstc;        // int  [cap+1] scratch, INF between steps
     size_t o_lp;            // double [cap+1] logprob table
     size_t o_cn;            // int  [cap+1] cl.n
-    size_t o_ml;            // double2 [cap+1][D] (mu, lambda)
+    size_t o_ml;            // double2 [cap+1][D] (mu, lambda): stand-alone cluster batches only
     size_t o_sb;            // double2 [cap+1][D] (Sigma, beta)
     size_t o_cnt;           // int  [cap+1][D][L]
     size_t o_nbs;           // long long [cap+1][D]
@@ -60,6 +60,7 @@ struct SweepArgs {
     int dl_lds;             // distinct-chosen-cluster list entries kept in LDS
     int pid_lds;            // 1: particle class ids [K][P] live in LDS
     int pp_lds;             // 1: per-particle step scratch (sid, kv) lives in LDS
+    int two_per_cu;         // 1: register-capped build so that two chains co-reside on a CU
     unsigned iter;
     long long n, n1;
     unsigned long long seed;

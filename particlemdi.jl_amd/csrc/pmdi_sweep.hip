@@ -168,8 +168,10 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
 }
 
 // ---------------------------------------------------------------------------
-template <int T>
-__global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
+// WPS = minimum waves per SIMD the register allocation must allow (2 co-resident chains per CU
+// at T = 512 need 4)
+template <int T, int WPS>
+__global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -269,7 +271,6 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
         // fresh clusters 1..nu+1 (:189,:194)
         if (d.kind == K_GAUSSIAN) {
             for (int it = tid; it < (nu + 1) * D; it += T) {
-                s.ml[D + it] = make_double2(0.0, 1.0);
                 s.sb[D + it] = make_double2(0.0, 0.5);
             }
         } else if (d.kind == K_CATEGORICAL) {
@@ -285,15 +286,14 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
             const int id = sh.lab[256 + u];
             if (!id || !flk[q]) continue;
             if (d.kind == K_GAUSSIAN) {
-                double2 ml = make_double2(0.0, 1.0), sb = make_double2(0.0, 0.5);
+                double2 sb = make_double2(0.0, 0.5);
                 int c = 0;
                 for (long long j = 0; j < n1 - 1; ++j) {
                     const int i = order[j];
                     if (s_in[(size_t)k * n + i] != u) continue;
                     ++c;
-                    gauss_add(d.xf[(size_t)i * D + q], c, ml, sb);
+                    gauss_add_sb(d.xf[(size_t)i * D + q], c, sb);
                 }
-                s.ml[(size_t)id * D + q] = ml;
                 s.sb[(size_t)id * D + q] = sb;
             } else if (d.kind == K_CATEGORICAL) {
                 int *cn_ = s.cnt + ((size_t)id * D + q) * d.L;
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                         if (!flk[q]) continue;
                         double ta = 0.0, tb = 0.0;
                         if (d.kind == K_GAUSSIAN) {
-                            gauss_terms(sh.xs[q], (double)cn, s.ml[(size_t)id * D + q], ta, tb);
+                            gauss_terms(sh.xs[q], (double)cn, gauss_ml(cn, s.sb[(size_t)id * D + q]), ta, tb);
                         } else if (d.kind == K_CATEGORICAL) {
                             const int x = ((const int *)sh.xs)[q];
                             ta = d.lhtab[d.maxcol[q] + 2 * cn];                 // log(nlevels_q + n)
@@ -672,9 +672,9 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                     else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
                     const bool on = flk[q];
                     if (d.kind == K_GAUSSIAN) {
-                        double2 ml = s.ml[(size_t)src * D + q], sb = s.sb[(size_t)src * D + q];
-                        if (on) gauss_add(sh.xs[q], nnew, ml, sb);
-                        if (on || dst != src) { s.ml[(size_t)dst * D + q] = ml; s.sb[(size_t)dst * D + q] = sb; }
+                        double2 sb = s.sb[(size_t)src * D + q];
+                        if (on) gauss_add_sb(sh.xs[q], nnew, sb);
+                        if (on || dst != src) s.sb[(size_t)dst * D + q] = sb;
                     } else if (d.kind == K_CATEGORICAL) {
                         const int x = ((const int *)sh.xs)[q];
                         const int *cs = s.cnt + ((size_t)src * D + q) * d.L;
@@ -823,10 +823,10 @@ __global__ void __launch_bounds__(T) pmdi_sweep_kernel(const SweepArgs a)
                         const long long it = b + tid;
                         const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
                         const bool mv = (it < nitems) && s.ncop[id] && s.firstc[id] != id;
-                        double2 ml = make_double2(0, 0), sb = make_double2(0, 0);
-                        if (mv) { ml = s.ml[(size_t)id * D + q]; sb = s.sb[(size_t)id * D + q]; }
+                        double2 sb = make_double2(0, 0);
+                        if (mv) sb = s.sb[(size_t)id * D + q];
                         __syncthreads();
-                        if (mv) { const int nid = s.firstc[id]; s.ml[(size_t)nid * D + q] = ml; s.sb[(size_t)nid * D + q] = sb; }
+                        if (mv) s.sb[(size_t)s.firstc[id] * D + q] = sb;
                     }
                 } else if (d.kind == K_CATEGORICAL) {
                     const long long itemsL = nitems * d.L;
@@ -942,21 +942,16 @@ size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T)
 hipError_t pmdi_launch_sweep(const SweepArgs &a, int n_chains, int T, hipStream_t stream)
 {
     const size_t lds = pmdi_sweep_lds_bytes(a, T);
-    hipError_t e = hipSuccess;
-    if (T == 1024) {
-        e = hipFuncSetAttribute((const void *)pmdi_sweep_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(pmdi_sweep_kernel<1024>, dim3(n_chains), dim3(1024), lds, stream, a);
-    } else if (T == 512) {
-        e = hipFuncSetAttribute((const void *)pmdi_sweep_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(pmdi_sweep_kernel<512>, dim3(n_chains), dim3(512), lds, stream, a);
-    } else if (T == 256) {
-        e = hipFuncSetAttribute((const void *)pmdi_sweep_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(pmdi_sweep_kernel<256>, dim3(n_chains), dim3(256), lds, stream, a);
-    } else {
-        return hipErrorInvalidValue;
-    }
+    const bool two = a.two_per_cu != 0;
+    const void *fn = nullptr;
+    if (T == 1024) fn = (const void *)pmdi_sweep_kernel<1024, 4>;
+    else if (T == 512) fn = two ? (const void *)pmdi_sweep_kernel<512, 4> : (const void *)pmdi_sweep_kernel<512, 2>;
+    else if (T == 256) fn = two ? (const void *)pmdi_sweep_kernel<256, 2> : (const void *)pmdi_sweep_kernel<256, 1>;
+    else return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    void *args[] = {(void *)&a};
+    e = hipLaunchKernel(fn, dim3(n_chains), dim3(T), args, lds, stream);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
