@@ -83,7 +83,9 @@ typedef struct {
     int64_t n_clones;      /* deepcopy at src/pmdi.jl:297 */
     int64_t max_id;        /* largest pool id live during the sweep */
     int64_t sum_classes;   /* mutation CDFs computed (fprob_done misses, src/pmdi.jl:231) */
-    int64_t reserved[3];
+    int64_t steps_fast;    /* steps whose working set fit the LDS tables */
+    int64_t steps_converted; /* steps that overflowed the LDS census and finished on the fallback */
+    int64_t steps_fallback;  /* steps run on the global-memory fallback (burn-in) */
 } pmdi_sweep_stats;
 
 /* Replaces the allocations of src/pmdi.jl:99-146 and the null-cluster

@@ -67,10 +67,11 @@ class _Config(C.Structure):
 
 class SweepStats(C.Structure):
     _fields_ = [("n_operations", C.c_int64), ("n_resamples", C.c_int64), ("n_clones", C.c_int64),
-                ("max_id", C.c_int64), ("sum_classes", C.c_int64), ("reserved", C.c_int64 * 3)]
+                ("max_id", C.c_int64), ("sum_classes", C.c_int64), ("steps_fast", C.c_int64),
+                ("steps_converted", C.c_int64), ("steps_fallback", C.c_int64)]
 
     def as_dict(self):
-        return {f: getattr(self, f) for f, _ in self._fields_[:5]}
+        return {f: getattr(self, f) for f, _ in self._fields_}
 
 
 _lib = None

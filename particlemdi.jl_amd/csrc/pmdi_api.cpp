@@ -477,6 +477,9 @@ int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t 
             stats[c].n_clones = stv[(size_t)c * 8 + ST_NCLONES];
             stats[c].max_id = stv[(size_t)c * 8 + ST_MAXID];
             stats[c].sum_classes = stv[(size_t)c * 8 + ST_SUMCLASSES];
+            stats[c].steps_fast = stv[(size_t)c * 8 + 5];
+            stats[c].steps_converted = stv[(size_t)c * 8 + 6];
+            stats[c].steps_fallback = stv[(size_t)c * 8 + 7];
         }
     return PMDI_OK;
 }

@@ -175,6 +175,35 @@ __device__ __forceinline__ bool wave_group(int key, bool valid, int &count)
     return leader;
 }
 
+// As wave_group, but every lane learns the lane id of its group's leader (lowest lane of the
+// group); `count` is set on leaders.
+__device__ __forceinline__ int wave_group_lead(int key, bool valid, int &count)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(valid);
+    int lead = lane;
+    count = 0;
+    while (active) {
+        const int l0 = __ffsll((long long)active) - 1;
+        const int k0 = __shfl(key, l0);
+        const bool mine = valid && key == k0;
+        const unsigned long long m = __ballot(mine);
+        if (mine) lead = l0;
+        if (lane == l0) count = __popcll(m);
+        active &= ~m;
+    }
+    return lead;
+}
+
+// number of set bits strictly below bit p of a bitmap of 32-bit words
+__device__ __forceinline__ int popc_below(const unsigned *bm, int p)
+{
+    const int w = p >> 5;
+    int n = 0;
+    for (int i = 0; i < w; ++i) n += __popc(bm[i]);
+    return n + __popc(bm[w] & ((1u << (p & 31)) - 1u));
+}
+
 // Julia Base.accumulate_pairwise! (base/accumulate.jl), the algorithm behind
 // cumsum(::Vector{Float64}) at src/misc.jl:29: in place on c[0..n).  Run by
 // one lane; the recursion is unrolled onto a small explicit stack.
@@ -257,6 +286,27 @@ __device__ __forceinline__ void gauss_terms(double x, double n, double2 ml, doub
     ta = 0.5 * log(ml.y / (n + 1.0));
     const double d = x - ml.x;
     tb = (0.5 * n + 1.0) * log(1.0 + (1.0 / (n + 1.0)) * (d * d) * ml.y);
+}
+
+// deepcopy (src/pmdi.jl:297) + cluster_add! (:300) of one feature of one chosen cluster:
+// statistics of pool id `src` plus the observation go to pool id `dst` (dst == src: in place).
+__device__ __forceinline__ void stats_update_one(const DsetDev &d, const KS &s, bool on, const double *xs,
+                                                 int src, int dst, int nnew, int D, int q)
+{
+    if (d.kind == K_GAUSSIAN) {
+        double2 sb = s.sb[(size_t)src * D + q];
+        if (on) gauss_add_sb(xs[q], nnew, sb);
+        if (on || dst != src) s.sb[(size_t)dst * D + q] = sb;
+    } else if (d.kind == K_CATEGORICAL) {
+        const int x = ((const int *)xs)[q];
+        const int *cs = s.cnt + ((size_t)src * D + q) * d.L;
+        int *cd = s.cnt + ((size_t)dst * D + q) * d.L;
+        if (dst != src) for (int l = 0; l < d.L; ++l) cd[l] = cs[l];
+        if (on) cd[x - 1] = cs[x - 1] + 1;
+    } else {
+        const int x = ((const int *)xs)[q];
+        s.nbs[(size_t)dst * D + q] = s.nbs[(size_t)src * D + q] + (on ? x : 0);
+    }
 }
 
 // calc_logprob(::NegBinomCluster) per-feature term: negbinom_cluster.jl:33-37;

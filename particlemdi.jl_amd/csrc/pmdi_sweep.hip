@@ -65,7 +65,8 @@ __device__ __forceinline__ int ht_find(const HT &h, int id)
 // ---------------------------------------------------------------------------
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
-        need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, kmaxid, kncls, kcur, knflag, lab, misc, ph,
+        need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v,
+        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, kmaxid, kncls, kcur, knflag, lab, misc, ph,
         fl, news, total;
 };
 
@@ -99,6 +100,17 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.h2k = take((size_t)a.ht_size * 4);
     c.h2a = take((size_t)a.ht_size * 4);
     c.h2b = take((size_t)a.ht_size * 4);
+    c.ktab_minp = take((size_t)a.item_cap * 4);
+    c.ktab_val = take((size_t)a.item_cap * 4);
+    c.klist = take((size_t)a.item_cap * 4);
+    c.kl_v = take((size_t)a.item_cap * 4);
+    c.kl_key = take((size_t)a.item_cap * 4);
+    c.fl_p = take((size_t)a.ht_size * 4);
+    c.fl_slot = take((size_t)a.ht_size * 4);
+    c.fl_nnew = take((size_t)a.ht_size * 4);
+    c.fl_tgt = take((size_t)a.ht_size * 4);
+    c.bm_fresh = take((size_t)((a.P >> 5) + 1) * 4);
+    c.bm_clone = take((size_t)((a.P >> 5) + 1) * 4);
     c.kmaxid = take(PMDI_KMAX_I * 4);
     c.kncls = take(PMDI_KMAX_I * 4);
     c.kcur = take(PMDI_KMAX_I * 4);
@@ -116,12 +128,14 @@ struct Sh {
     unsigned long long *scan;
     int *pid, *sid, *kv, *lead_of, *slot_of, *cl_lead, *cl_val, *need, *need_slot, *item_id, *dl, *dl_slot;
     HT h1, h2;
+    int *ktab_minp, *ktab_val, *klist, *kl_v, *kl_key, *fl_p, *fl_slot, *fl_nnew, *fl_tgt;
+    unsigned *bm_fresh, *bm_clone;
     int *kmaxid, *kncls, *kcur, *knflag, *lab, *misc;
     long long *ph;
     unsigned char *fl, *news;
 };
 
-enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2 };
+enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6 };
 
 // class list of dataset k: slot r -> leader particle / class value.  The first cls_lds slots
 // live in LDS, the rest (burn-in only) in global memory.
@@ -197,6 +211,11 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
         sh.item_id = (int *)(smem + c.item_id); sh.dl = (int *)(smem + c.dl); sh.dl_slot = (int *)(smem + c.dl_slot);
         sh.h1.key = (int *)(smem + c.h1k); sh.h1.a = (int *)(smem + c.h1a); sh.h1.b = nullptr; sh.h1.mask = (unsigned)H - 1;
         sh.h2.key = (int *)(smem + c.h2k); sh.h2.a = (int *)(smem + c.h2a); sh.h2.b = (int *)(smem + c.h2b); sh.h2.mask = (unsigned)H - 1;
+        sh.ktab_minp = (int *)(smem + c.ktab_minp); sh.ktab_val = (int *)(smem + c.ktab_val);
+        sh.klist = (int *)(smem + c.klist); sh.kl_v = (int *)(smem + c.kl_v); sh.kl_key = (int *)(smem + c.kl_key);
+        sh.fl_p = (int *)(smem + c.fl_p); sh.fl_slot = (int *)(smem + c.fl_slot); sh.fl_nnew = (int *)(smem + c.fl_nnew);
+        sh.fl_tgt = (int *)(smem + c.fl_tgt);
+        sh.bm_fresh = (unsigned *)(smem + c.bm_fresh); sh.bm_clone = (unsigned *)(smem + c.bm_clone);
         sh.kmaxid = (int *)(smem + c.kmaxid); sh.kncls = (int *)(smem + c.kncls); sh.kcur = (int *)(smem + c.kcur); sh.knflag = (int *)(smem + c.knflag);
         sh.lab = (int *)(smem + c.lab); sh.misc = (int *)(smem + c.misc); sh.ph = (long long *)(smem + c.ph);
         sh.fl = smem + c.fl; sh.news = smem + c.news;
@@ -211,6 +230,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
     int *pstar_raw = a.partstar + (size_t)chain * P;
 
     long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
+    long long st_fast = 0, st_conv = 0, st_slow = 0;
     long long ph_last = 0;
     int ph_cur = 0;
 #define PH(i_)                                                                  \
@@ -227,6 +247,8 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
     for (int p = tid; p < P; p += T) sh.lw[p] = a.lw_init;
     for (int c = tid; c <= P; c += T) { sh.lead_of[c] = PMDI_INF_I; sh.slot_of[c] = 0; }
     for (int e = tid; e < H; e += T) { sh.h1.key[e] = 0; sh.h1.a[e] = 0; sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+    for (int e = tid; e < a.item_cap; e += T) sh.ktab_minp[e] = PMDI_INF_I;
+    for (int e = tid; e <= (P >> 5); e += T) { sh.bm_fresh[e] = 0; sh.bm_clone[e] = 0; }
 
     // ---- reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207) ----
     for (int k = 0; k < K; ++k) {
@@ -513,187 +535,381 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
             }
             __syncthreads();
 
-            // -- C: allocation draw (:251-265), class key, chosen-cluster census
+            // -- C..F: allocation draw (:251-265), class ids (:266-272), copy-on-write update of the
+            // chosen clusters (:275-310).  Fast path (the step's tables fit LDS): classes come from a
+            // (class, label) key table, ranks "in particle order" from LDS bitmaps + popcounts, no
+            // block-wide scans.  Fallback (burn-in): per-particle keys, ballot scans, global tables.
             PH(5);
             if (small) {
                 for (int j = tid; j < nneed; j += T) { const int sl = sh.need_slot[j]; sh.h1.key[sl] = 0; sh.h1.a[sl] = 0; }
                 if (tid == 0) sh.misc[M_NEED] = 0;
             }
-            for (int pb = 0; pb < P; pb += T) {
-                const int p = pb + tid;
-                const bool valid = p < P;
-                int ns = 0, c = 0, key = 0;
-                bool fresh = false;
-                if (valid) {
-                    const int cls = pidk[p];
-                    const double *row = cdfp + (size_t)sh.slot_of[cls] * (N + 1);
-                    if (p != 0) {
-                        const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
-                        for (int t = 0; t < N - 1; ++t) {
-                            if (row[ns] > u) break;
-                            ++ns;
-                        }
-                    } else {
-                        ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
-                    }
-                    sh.lw[p] += row[N];
-                    key = (cls - 1) * N + ns;
-                    c = part[ns * P + p];                        // sstar_id (:264)
-                    const int v = s.newid[key];
-                    sidp[p] = c;
-                    kvp[p] = v;
-                    sh.news[k * P + p] = (unsigned char)ns;
-                    s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
-                    fresh = v <= 0;
-                }
-                int cnt;
-                if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
-                if (wave_group(c, valid, cnt)) {
-                    bool won;
-                    const int slot = ht_insert(sh.h2, c, won, 48);
-                    if (slot < 0) sh.misc[M_OVF] = 1;
-                    else { atomicAdd(&sh.h2.a[slot], cnt); atomicMin(&sh.h2.b[slot], p); }
-                }
-            }
-            __syncthreads();
-            const bool gcensus = sh.misc[M_OVF] != 0;
-            PH(13);
-            if (gcensus) {   // too many distinct clusters for the LDS table: per-id tables in global memory
-                for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+            bool fast = small;
+            bool converted = false;
+            int nd = 0, nclone = 0, new_ncls = 0;
+            if (fast) {
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
                     const bool valid = p < P;
-                    const int c = valid ? sidp[p] : 0;
-                    int cnt;
-                    if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
+                    int ns = 0, c = 0, kidx = 0;
+                    if (valid) {
+                        const int r = sh.slot_of[pidk[p]];
+                        const double *row = sh.cdf + (size_t)r * (N + 1);
+                        if (p != 0) {
+                            const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                            // first label whose CDF exceeds u (:252-260); the CDF is non-decreasing, so
+                            // that is the number of leading entries that do not exceed u
+                            for (int t = 0; t < N - 1; ++t) ns += (row[t] > u) ? 0 : 1;
+                        } else {
+                            ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
+                        }
+                        sh.lw[p] += row[N];
+                        c = part[ns * P + p];                        // sstar_id (:264)
+                        kidx = r * N + ns;
+                        sidp[p] = kidx;
+                        sh.news[k * P + p] = (unsigned char)ns;
+                        s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
+                    }
+                    const unsigned long long vmask = __ballot(valid);
+                    const int k0 = __shfl(kidx, 0), c0 = __shfl(c, 0);
+                    int slot = -1;
+                    if (__all(!valid || (kidx == k0 && c == c0))) {     // the whole wave agrees: one lane speaks
+                        if (lane == 0 && valid) {
+                            atomicMin(&sh.ktab_minp[k0], p);
+                            bool won;
+                            slot = ht_insert(sh.h2, c0, won, 48);
+                            if (slot < 0) sh.misc[M_OVF] = 1;
+                            else { atomicAdd(&sh.h2.a[slot], __popcll(vmask)); atomicMin(&sh.h2.b[slot], p); }
+                        }
+                        slot = __shfl(slot, 0);
+                    } else {
+                        if (valid) atomicMin(&sh.ktab_minp[kidx], p);
+                        int cnt;
+                        const int lead = wave_group_lead(c, valid, cnt);
+                        if (valid && lead == lane) {
+                            bool won;
+                            slot = ht_insert(sh.h2, c, won, 48);
+                            if (slot < 0) sh.misc[M_OVF] = 1;
+                            else { atomicAdd(&sh.h2.a[slot], cnt); atomicMin(&sh.h2.b[slot], p); }
+                        }
+                        slot = __shfl(slot, lead);
+                    }
+                    if (valid) kvp[p] = slot;
                 }
                 __syncthreads();
-            }
-
-            // -- D: ranks in particle order: fresh class keys (:266-269) and distinct chosen
-            // clusters, clone-or-in-place (:276-299)
-            PH(6);
-            unsigned long long carry = 0;
-            for (int pb = 0; pb < P; pb += T) {
-                const int p = pb + tid;
-                const bool valid = p < P;
-                int key = 0, c = 0, slot = 0, ncp = 0;
-                bool fk = false, fc = false, nc = false;
-                if (valid) {
-                    c = sidp[p];
-                    if (kvp[p] <= 0) {
-                        key = (pidk[p] - 1) * N + sh.news[k * P + p];
-                        fk = s.newid[key] == p - P;
-                    }
-                    if (gcensus) { fc = s.firstc[c] == p; if (fc) ncp = s.ncop[c]; }
-                    else { slot = ht_find(sh.h2, c); fc = sh.h2.b[slot] == p; ncp = sh.h2.a[slot]; }
-                    nc = fc && (ncp != s.counts[c]);
-                }
-                unsigned long long tot;
-                const unsigned long long ex = block_flag_scan<T>(fk, fc, nc, tot, sh.scan) + carry;
-                if (fk) s.newid[key] = (int)(ex & 0xfffffull) + 1;
-                if (fc) {
-                    const int rc = (int)((ex >> 20) & 0xfffffull);
-                    const int tgt = nc ? maxid + (int)(ex >> 40) + 1 : c;
-                    if (tgt <= cap) {
-                        const int nnew = s.cn[c] + 1;
-                        if (nc) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }   // (:293-294)
-                        s.cn[tgt] = nnew;
-                        if (rc < a.dl_lds) {
-                            sh.dl[rc] = c; sh.dl[a.dl_lds + rc] = tgt; sh.dl[2 * a.dl_lds + rc] = nnew;
-                            sh.dl_slot[rc] = slot;
-                        } else {
-                            s.dl[rc] = c; s.dl[P + rc] = tgt; s.dl[2 * P + rc] = nnew;
+                if (sh.misc[M_OVF]) {
+                    // too many distinct chosen clusters for the LDS census: hand this step to the
+                    // fallback (per-particle keys, per-id tables in global memory)
+                    fast = false;
+                    converted = true;
+                    for (int w = tid; w < items; w += T) sh.ktab_minp[w] = PMDI_INF_I;
+                    for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+                    for (int pb = 0; pb < P; pb += T) {
+                        const int p = pb + tid;
+                        const bool valid = p < P;
+                        int c = 0, key = 0;
+                        bool fresh = false;
+                        if (valid) {
+                            const int ns = sh.news[k * P + p];
+                            key = (pidk[p] - 1) * N + ns;
+                            c = part[ns * P + p];
+                            const int v = s.newid[key];
+                            sidp[p] = c;
+                            kvp[p] = v;
+                            fresh = v <= 0;
                         }
-                        if (gcensus) s.ncop[c] = tgt; else sh.h2.a[slot] = tgt;   // chosen id -> updated id
+                        int cnt;
+                        if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
+                        if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (fast) {
+                // -- D'1: the touched (class, label) keys and the first particle of every chosen cluster
+                PH(6);
+                for (int w = tid; w < items; w += T) {
+                    const int mp = sh.ktab_minp[w];
+                    if (mp != PMDI_INF_I) {
+                        const int r = w / N, ns = w - r * N;
+                        const int key = (cl.val(r) - 1) * N + ns;
+                        const int v = (a.q1 == 1) ? 0 : s.newid[key];          // (:266)
+                        const int j = atomicAdd(&sh.misc[M_NK], 1);
+                        sh.klist[j] = w; sh.kl_v[j] = v; sh.kl_key[j] = key;
+                        if (v <= 0) atomicOr(&sh.bm_fresh[mp >> 5], 1u << (mp & 31));
                     }
                 }
-                carry += tot;
-            }
-            const int nd = (int)((carry >> 20) & 0xfffffull);
-            const int nclone = (int)(carry >> 40);
-            if (maxid + nclone > cap) failed = 1;
-            __syncthreads();
-            if (failed) break;
-
-            // -- E: apply: new class ids, remap cloned labels (:301-308)
-            PH(7);
-            for (int pb = 0; pb < P; pb += T) {
-                const int p = pb + tid;
-                const bool valid = p < P;
-                int newcls = 0;
-                if (valid) {
-                    const int ns = sh.news[k * P + p];
-                    const int key = (pidk[p] - 1) * N + ns;
-                    const int v = kvp[p];
-                    newcls = (v <= 0) ? s.newid[key] : v;
-                    const int c = sidp[p];
-                    const int tgt = gcensus ? s.ncop[c] : sh.h2.a[ht_find(sh.h2, c)];
-                    if (tgt != c) part[ns * P + p] = tgt;
-                    pidk[p] = newcls;
-                    kvp[p] = key;
-                }
-                int cnt;
-                if (wave_group(newcls, valid, cnt)) atomicMin(&sh.lead_of[newcls], p);
-            }
-            __syncthreads();
-
-            // -- F: class list for the next step; scratch clean-up; sufficient-statistic update
-            // of every distinct chosen cluster (deepcopy + cluster_add!, :297,:300):
-            // lanes = (cluster, feature)
-            PH(8);
-            {
-                unsigned long long ccarry = 0;
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
-                    const bool valid = p < P;
-                    const int cls = valid ? pidk[p] : 0;
-                    const bool isl = valid && sh.lead_of[cls] == p;
-                    unsigned long long tot;
-                    const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, sh.scan) + ccarry;
-                    if (isl) { cl.set((int)ex, p, cls); sh.slot_of[cls] = (int)ex; }
-                    if (valid && a.q1 == 1) s.newid[kvp[p]] = 0;   // corrected mode: new_id per step
-                    ccarry += tot;
-                }
-                if (gcensus) {
-                    for (int j = tid; j < nd; j += T) {
-                        const int c = j < a.dl_lds ? sh.dl[j] : s.dl[j];
-                        s.ncop[c] = 0; s.firstc[c] = PMDI_INF_I;
+                    if (p < P) {
+                        const int slot = kvp[p];
+                        if (sh.h2.b[slot] == p) {
+                            const int c = sh.h2.key[slot];
+                            const bool needs = sh.h2.a[slot] != s.counts[c];       // ncopies == counts ? (:286)
+                            const int j = atomicAdd(&sh.misc[M_NF], 1);
+                            sh.fl_p[j] = needs ? (p | 0x40000000) : p;
+                            sh.fl_slot[j] = slot;
+                            sh.fl_nnew[j] = s.cn[c] + 1;
+                            if (needs) atomicOr(&sh.bm_clone[p >> 5], 1u << (p & 31));
+                        }
                     }
-                } else if (nd <= a.dl_lds) {
-                    for (int j = tid; j < nd; j += T) { const int sl = sh.dl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
-                } else {
-                    for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+                }
+                __syncthreads();
+                // -- D'2: ranks in particle order by popcounts below the particle's bit
+                PH(7);
+                const int nk = sh.misc[M_NK], nf = sh.misc[M_NF];
+                if (wave == 0) {
+                    for (int j0 = 0; j0 < nk; j0 += 64) {
+                        const int j = j0 + lane;
+                        if (j < nk) {
+                            const int w = sh.klist[j];
+                            int v = sh.kl_v[j];
+                            if (v <= 0) {                                           // curr_id += 1 (:267-269)
+                                v = 1 + popc_below(sh.bm_fresh, sh.ktab_minp[w]);
+                                if (a.q1 == 0) s.newid[sh.kl_key[j]] = v;
+                            }
+                            sh.kl_v[j] = v;
+                            sh.ktab_val[w] = v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // classes of the next step: one per distinct value, leader = lowest first particle
+                    for (int j0 = 0; j0 < nk; j0 += 64) {
+                        const int j = j0 + lane;
+                        if (j < nk) {
+                            const int v = sh.kl_v[j], mp = sh.ktab_minp[sh.klist[j]];
+                            int rep = 1;
+                            for (int j2 = 0; j2 < nk; ++j2)
+                                if (sh.kl_v[j2] == v && sh.ktab_minp[sh.klist[j2]] < mp) rep = 0;
+                            sh.kl_key[j] = rep;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    int nrep = 0;
+                    for (int j0 = 0; j0 < nk; j0 += 64) {
+                        const int j = j0 + lane;
+                        const bool rep = (j < nk) && sh.kl_key[j];
+                        if (rep) {
+                            const int mp = sh.ktab_minp[sh.klist[j]];
+                            int slot = 0;
+                            for (int j2 = 0; j2 < nk; ++j2)
+                                if (sh.kl_key[j2] && sh.ktab_minp[sh.klist[j2]] < mp) ++slot;
+                            cl.set(slot, mp, sh.kl_v[j]);
+                        }
+                        nrep += __popcll(__ballot(rep));
+                    }
+                    if (lane == 0) { sh.misc[M_NCLS] = nrep; sh.misc[M_NCLONE] = popc_below(sh.bm_clone, P); }
+                }
+                for (int j = tid; j < nf; j += T) {
+                    const int pp = sh.fl_p[j];
+                    const bool needs = (pp & 0x40000000) != 0;
+                    const int p = pp & 0x3fffffff;
+                    const int slot = sh.fl_slot[j];
+                    const int c = sh.h2.key[slot], ncp = sh.h2.a[slot];
+                    const int tgt = needs ? maxid + 1 + popc_below(sh.bm_clone, p) : c;    // (:290-292)
+                    sh.fl_p[j] = c;
+                    sh.fl_tgt[j] = tgt;
+                    if (tgt <= cap) {
+                        if (needs) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }             // (:293-294)
+                        s.cn[tgt] = sh.fl_nnew[j];
+                        sh.h2.a[slot] = tgt;                                                // chosen id -> updated id
+                    }
+                }
+                __syncthreads();
+                nd = nf;
+                nclone = sh.misc[M_NCLONE];
+                new_ncls = sh.misc[M_NCLS];
+                if (maxid + nclone > cap) { failed = 1; break; }
+                // -- E': apply (:301-308), sufficient statistics (:297,:300), table clean-up
+                PH(8);
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    if (p < P) {
+                        const int slot = kvp[p];
+                        const int c = sh.h2.key[slot], tgt = sh.h2.a[slot];
+                        if (tgt != c) part[(int)sh.news[k * P + p] * P + p] = tgt;
+                        pidk[p] = sh.ktab_val[sidp[p]];
+                    }
                 }
                 for (int it = tid; it < nd * D; it += T) {
                     const int j = it / D, q = it - j * D;
-                    int src, dst, nnew;
-                    if (j < a.dl_lds) { src = sh.dl[j]; dst = sh.dl[a.dl_lds + j]; nnew = sh.dl[2 * a.dl_lds + j]; }
-                    else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
-                    const bool on = flk[q];
-                    if (d.kind == K_GAUSSIAN) {
-                        double2 sb = s.sb[(size_t)src * D + q];
-                        if (on) gauss_add_sb(sh.xs[q], nnew, sb);
-                        if (on || dst != src) s.sb[(size_t)dst * D + q] = sb;
-                    } else if (d.kind == K_CATEGORICAL) {
-                        const int x = ((const int *)sh.xs)[q];
-                        const int *cs = s.cnt + ((size_t)src * D + q) * d.L;
-                        int *cd = s.cnt + ((size_t)dst * D + q) * d.L;
-                        if (dst != src) for (int l = 0; l < d.L; ++l) cd[l] = cs[l];
-                        if (on) cd[x - 1] = cs[x - 1] + 1;
-                    } else {
-                        const int x = ((const int *)sh.xs)[q];
-                        s.nbs[(size_t)dst * D + q] = s.nbs[(size_t)src * D + q] + (on ? x : 0);
+                    stats_update_one(d, s, flk[q], sh.xs, sh.fl_p[j], sh.fl_tgt[j], sh.fl_nnew[j], D, q);
+                }
+                for (int j = tid; j < nk; j += T) sh.ktab_minp[sh.klist[j]] = PMDI_INF_I;
+                for (int w = tid; w <= (P >> 5); w += T) { sh.bm_fresh[w] = 0; sh.bm_clone[w] = 0; }
+                __syncthreads();
+                for (int j = tid; j < nf; j += T) { const int sl = sh.fl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
+                if (tid == 0) { sh.misc[M_NK] = 0; sh.misc[M_NF] = 0; }
+            } else {
+                bool gcensus = converted;
+                if (!converted) {
+                    for (int pb = 0; pb < P; pb += T) {
+                        const int p = pb + tid;
+                        const bool valid = p < P;
+                        int ns = 0, c = 0, key = 0;
+                        bool fresh = false;
+                        if (valid) {
+                            const int cls = pidk[p];
+                            const double *row = cdfp + (size_t)sh.slot_of[cls] * (N + 1);
+                            if (p != 0) {
+                                const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                                for (int t = 0; t < N - 1; ++t) {
+                                    if (row[ns] > u) break;
+                                    ++ns;
+                                }
+                            } else {
+                                ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
+                            }
+                            sh.lw[p] += row[N];
+                            key = (cls - 1) * N + ns;
+                            c = part[ns * P + p];                        // sstar_id (:264)
+                            const int v = s.newid[key];
+                            sidp[p] = c;
+                            kvp[p] = v;
+                            sh.news[k * P + p] = (unsigned char)ns;
+                            s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
+                            fresh = v <= 0;
+                        }
+                        int cnt;
+                        if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
+                        if (wave_group(c, valid, cnt)) {
+                            bool won;
+                            const int slot = ht_insert(sh.h2, c, won, 48);
+                            if (slot < 0) sh.misc[M_OVF] = 1;
+                            else { atomicAdd(&sh.h2.a[slot], cnt); atomicMin(&sh.h2.b[slot], p); }
+                        }
+                    }
+                    __syncthreads();
+                    gcensus = sh.misc[M_OVF] != 0;
+                    PH(13);
+                    if (gcensus) {   // too many distinct clusters for the LDS table: per-id tables in global memory
+                        for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+                        for (int pb = 0; pb < P; pb += T) {
+                            const int p = pb + tid;
+                            const bool valid = p < P;
+                            const int c = valid ? sidp[p] : 0;
+                            int cnt;
+                            if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
+                        }
+                        __syncthreads();
                     }
                 }
-                st_nops += maxid;                     // src/__pmdi.jl:187
-                st_sumcls += ncls;
-                st_nclones += nclone;
-                if (maxid + nclone > st_maxid) st_maxid = maxid + nclone;
+
+                // -- D: ranks in particle order: fresh class keys (:266-269) and distinct chosen
+                // clusters, clone-or-in-place (:276-299)
+                PH(6);
+                unsigned long long carry = 0;
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    int key = 0, c = 0, slot = 0, ncp = 0;
+                    bool fk = false, fc = false, nc = false;
+                    if (valid) {
+                        c = sidp[p];
+                        if (kvp[p] <= 0) {
+                            key = (pidk[p] - 1) * N + sh.news[k * P + p];
+                            fk = s.newid[key] == p - P;
+                        }
+                        if (gcensus) { fc = s.firstc[c] == p; if (fc) ncp = s.ncop[c]; }
+                        else { slot = ht_find(sh.h2, c); fc = sh.h2.b[slot] == p; ncp = sh.h2.a[slot]; }
+                        nc = fc && (ncp != s.counts[c]);
+                    }
+                    unsigned long long tot;
+                    const unsigned long long ex = block_flag_scan<T>(fk, fc, nc, tot, sh.scan) + carry;
+                    if (fk) s.newid[key] = (int)(ex & 0xfffffull) + 1;
+                    if (fc) {
+                        const int rc = (int)((ex >> 20) & 0xfffffull);
+                        const int tgt = nc ? maxid + (int)(ex >> 40) + 1 : c;
+                        if (tgt <= cap) {
+                            const int nnew = s.cn[c] + 1;
+                            if (nc) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }   // (:293-294)
+                            s.cn[tgt] = nnew;
+                            if (rc < a.dl_lds) {
+                                sh.dl[rc] = c; sh.dl[a.dl_lds + rc] = tgt; sh.dl[2 * a.dl_lds + rc] = nnew;
+                                sh.dl_slot[rc] = slot;
+                            } else {
+                                s.dl[rc] = c; s.dl[P + rc] = tgt; s.dl[2 * P + rc] = nnew;
+                            }
+                            if (gcensus) s.ncop[c] = tgt; else sh.h2.a[slot] = tgt;   // chosen id -> updated id
+                        }
+                    }
+                    carry += tot;
+                }
+                nd = (int)((carry >> 20) & 0xfffffull);
+                nclone = (int)(carry >> 40);
+                if (maxid + nclone > cap) failed = 1;
                 __syncthreads();
-                for (int r = tid; r < (int)ccarry; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
-                if (tid == 0) { sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = (int)ccarry; }
+                if (failed) break;
+
+                // -- E: apply: new class ids, remap cloned labels (:301-308)
+                PH(7);
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    int newcls = 0;
+                    if (valid) {
+                        const int ns = sh.news[k * P + p];
+                        const int key = (pidk[p] - 1) * N + ns;
+                        const int v = kvp[p];
+                        newcls = (v <= 0) ? s.newid[key] : v;
+                        const int c = sidp[p];
+                        const int tgt = gcensus ? s.ncop[c] : sh.h2.a[ht_find(sh.h2, c)];
+                        if (tgt != c) part[ns * P + p] = tgt;
+                        pidk[p] = newcls;
+                        kvp[p] = key;
+                    }
+                    int cnt;
+                    if (wave_group(newcls, valid, cnt)) atomicMin(&sh.lead_of[newcls], p);
+                }
+                __syncthreads();
+
+                // -- F: class list for the next step; scratch clean-up; sufficient-statistic update
+                // of every distinct chosen cluster (deepcopy + cluster_add!, :297,:300):
+                // lanes = (cluster, feature)
+                PH(8);
+                {
+                    unsigned long long ccarry = 0;
+                    for (int pb = 0; pb < P; pb += T) {
+                        const int p = pb + tid;
+                        const bool valid = p < P;
+                        const int cls = valid ? pidk[p] : 0;
+                        const bool isl = valid && sh.lead_of[cls] == p;
+                        unsigned long long tot;
+                        const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, sh.scan) + ccarry;
+                        if (isl) { cl.set((int)ex, p, cls); sh.slot_of[cls] = (int)ex; }
+                        if (valid && a.q1 == 1) s.newid[kvp[p]] = 0;   // corrected mode: new_id per step
+                        ccarry += tot;
+                    }
+                    if (gcensus) {
+                        for (int j = tid; j < nd; j += T) {
+                            const int c = j < a.dl_lds ? sh.dl[j] : s.dl[j];
+                            s.ncop[c] = 0; s.firstc[c] = PMDI_INF_I;
+                        }
+                    } else if (nd <= a.dl_lds) {
+                        for (int j = tid; j < nd; j += T) { const int sl = sh.dl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
+                    } else {
+                        for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+                    }
+                    for (int it = tid; it < nd * D; it += T) {
+                        const int j = it / D, q = it - j * D;
+                        int src, dst, nnew;
+                        if (j < a.dl_lds) { src = sh.dl[j]; dst = sh.dl[a.dl_lds + j]; nnew = sh.dl[2 * a.dl_lds + j]; }
+                        else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
+                        stats_update_one(d, s, flk[q], sh.xs, src, dst, nnew, D, q);
+                    }
+                    new_ncls = (int)ccarry;
+                    __syncthreads();
+                    for (int r = tid; r < new_ncls; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
+                }
             }
+            if (fast) ++st_fast; else if (converted) ++st_conv; else ++st_slow;
+            st_nops += maxid;                     // src/__pmdi.jl:187
+            st_sumcls += ncls;
+            st_nclones += nclone;
+            if (maxid + nclone > st_maxid) st_maxid = maxid + nclone;
+            if (tid == 0) { sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = new_ncls; }
             __syncthreads();
         }
         if (failed) break;
@@ -923,6 +1139,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
             long long *st = a.stats + (size_t)chain * 8;
             st[ST_NOPS] = st_nops; st[ST_NRESAMPLE] = st_nres; st[ST_NCLONES] = st_nclones;
             st[ST_MAXID] = st_maxid; st[ST_SUMCLASSES] = st_sumcls;
+            st[5] = st_fast; st[6] = st_conv; st[7] = st_slow;
             a.err[chain] = 0;
         }
     }

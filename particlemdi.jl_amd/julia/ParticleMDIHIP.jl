@@ -53,7 +53,9 @@ struct CSweepStats
     n_clones::Int64
     max_id::Int64
     sum_classes::Int64
-    reserved::NTuple{3, Int64}
+    steps_fast::Int64
+    steps_converted::Int64
+    steps_fallback::Int64
 end
 
 device_kind(::Type{ParticleMDI.GaussianCluster}) = Int32(0)
@@ -160,7 +162,7 @@ function pmdi(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float64, ite
         s_out = similar(s)
         logweight = zeros(Float64, particles)
         p_star = Ref{Int64}(0)
-        stats = Ref(CSweepStats(0, 0, 0, 0, 0, (0, 0, 0)))
+        stats = Ref(CSweepStats(0, 0, 0, 0, 0, 0, 0, 0))
         flags_out = similar(flags)
         for it in 1:iter
             shuffle!(order_obs)                                        # src/pmdi.jl:172

@@ -98,6 +98,30 @@ def test_edges(pkg, O, N, P, n1, n):
     _compare_run(pkg, O, [g, c], ["gaussian", "categorical"], N, P, 2, 70 + N, n1)
 
 
+def test_all_three_step_paths_are_exercised(pkg, O):
+    """fast (LDS tables), converted (LDS census overflow) and fallback (burn-in) steps all occur
+    somewhere in this run, and the result is still the oracle's."""
+    rng = np.random.default_rng(11)
+    n = 400
+    x = rng.normal(size=(n, 3))                    # no structure: particles diverge quickly
+    N, P = 16, 1024
+    g = GpuRunner(pkg, [x], ["gaussian"], N, P, 5, 0)
+    o = O.Oracle([x], ["gaussian"], N, P, seed=5)
+    s = rng.integers(1, N + 1, size=(n, 1))
+    tot = {"steps_fast": 0, "steps_converted": 0, "steps_fallback": 0}
+    for it in range(1, 4):
+        order = rng.permutation(n) + 1
+        Pi, Phi = random_hypers(rng, N, 1)
+        rg = g.sweep(it, s, order, 100, Pi, Phi, None)
+        ro = o.sweep(it, s, order, 100, Pi, Phi)
+        assert (rg["s"] == ro["s"]).all() and rg["p_star"] == ro["p_star"]
+        assert rg["stats"]["n_clones"] == ro["stats"]["n_clones"]
+        for key in tot:
+            tot[key] += rg["stats"][key]
+        s = ro["s"]
+    assert all(v > 0 for v in tot.values()), tot
+
+
 def test_chains_are_independent_and_seeded(pkg, O):
     rng = np.random.default_rng(3)
     data, kinds = make_mixed(rng, 150)
