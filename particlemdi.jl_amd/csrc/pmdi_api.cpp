@@ -100,14 +100,14 @@ struct pmdi_handle {
     int T = 0;
     long long cap = 0;
     int Dmax = 0, sumD = 0, npairs = 1;
-    int terms_cap = 0, item_cap = 0, ht_size = 0, cls_lds = 0, dl_lds = 0, pid_lds = 0, pp_lds = 0, two_per_cu = 0;
+    int terms_cap = 0, pid_lds = 0, pp_lds = 0, two_per_cu = 0;
     bool phase_on = false;
     hipStream_t stream = nullptr;
     DsetDev ds[PMDI_KMAX_I]{};
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
     bool swept = false;
@@ -151,7 +151,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.Dmax = h->Dmax; a.sumD = h->sumD; a.npairs = h->npairs;
     a.q1 = h->cfg.q1_mode; a.q2 = h->cfg.q2_mode;
     a.terms_cap = h->terms_cap;
-    a.item_cap = h->item_cap; a.ht_size = h->ht_size; a.cls_lds = h->cls_lds; a.dl_lds = h->dl_lds; a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
+    a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
@@ -172,7 +172,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -304,12 +304,8 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         if (tc < (h->T / 64) * 128) tc = (h->T / 64) * 128;   // per-wave CDF exchange areas
         if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
         h->terms_cap = tc;
-        h->item_cap = env_int("PMDI_ITEM_CAP", 256);
-        h->ht_size = env_int("PMDI_HT_SIZE", 512);
-        if (h->item_cap < 2 * N) h->item_cap = 2 * N;
-        while (h->ht_size < 2 * h->item_cap || (h->ht_size & (h->ht_size - 1))) h->ht_size = (h->ht_size | (h->ht_size - 1)) + 1;
-        h->two_per_cu = env_int("PMDI_TWO_PER_CU", 0);
-        h->cls_lds = h->item_cap / 2; h->dl_lds = env_int("PMDI_DL_LDS", 128);
+        if (2 * N > PMDI_ITEM_CAP) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));
+        h->two_per_cu = env_int("PMDI_TWO_PER_CU", 1);
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         SweepArgs a;
         h->pid_lds = 1; h->pp_lds = 1;
@@ -329,7 +325,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if ((rc = h->d_usc.ensure((size_t)C * P * 8)) || (rc = h->d_partstar.ensure((size_t)C * P * 4)) ||
         (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
-        (rc = h->d_phase.ensure((size_t)C * 16 * 8)))
+        (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))))
         return bail(rc);
 
     // null-cluster marginal (src/pmdi.jl:120-128): all rows in one cluster, all features on
@@ -400,7 +396,7 @@ int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const i
     a.trace = nullptr; a.trace_on = 0;
     a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
     hipStream_t st = (hipStream_t)stream;   // used verbatim: NULL is the device's default (null) stream
-    hipError_t e = pmdi_launch_sweep(a, h->cfg.n_chains, h->T, st);
+    hipError_t e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, h->cfg.n_chains, h->T, st);
     if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
     h->swept = true; h->last_n1 = n1;
     return PMDI_OK;
@@ -451,7 +447,7 @@ int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t 
     a.stats = (long long *)h->d_stats.p; a.err = (int *)h->d_err.p;
     a.trace = trace ? (double *)h->d_trace.p : nullptr; a.trace_on = trace ? 1 : 0;
     a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
-    hipError_t e = pmdi_launch_sweep(a, C, h->T, h->stream);
+    hipError_t e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, h->stream);
     if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
     std::vector<int> so(s32.size()), ps(C), er(C);
     std::vector<long long> stv((size_t)C * 8);

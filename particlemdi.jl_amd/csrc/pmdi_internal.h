@@ -7,6 +7,14 @@
 #define PMDI_KMAX_I 8
 #define PMDI_INF_I 0x7fffffff
 
+// Compile-time capacities of the per-chain LDS tables (a step whose working set exceeds them
+// runs on the global-memory fallback).  Constants, so that the addresses of these tables fold
+// into instruction immediates instead of occupying registers.
+#define PMDI_ITEM_CAP 256   // (class, label) items of a step
+#define PMDI_HT_SIZE 512    // entries per hash table (>= 2 * PMDI_ITEM_CAP, power of two)
+#define PMDI_CLS_LDS 128    // class-list slots per dataset kept in LDS
+#define PMDI_DL_LDS 128     // distinct-chosen-cluster entries kept in LDS (fallback path)
+
 enum { K_GAUSSIAN = 0, K_CATEGORICAL = 1, K_NEGBINOM = 2 };
 enum { SITE_DRAW = 0, SITE_RESAMPLE_U = 1, SITE_RESAMPLE_SLOT = 2, SITE_PSTAR = 3, SITE_FEATSEL = 4 };
 enum { ST_NOPS = 0, ST_NRESAMPLE = 1, ST_NCLONES = 2, ST_MAXID = 3, ST_SUMCLASSES = 4 };
@@ -54,10 +62,6 @@ struct SweepArgs {
     int K, N, P, cap;
     int Dmax, sumD, npairs, q1, q2, trace_on;
     int terms_cap;          // doubles in the LDS term buffer
-    int item_cap;           // (class, label) items a step may have to use the LDS tables
-    int ht_size;            // entries of each LDS hash table (power of two, >= 2*item_cap)
-    int cls_lds;            // class-list slots per dataset kept in LDS
-    int dl_lds;             // distinct-chosen-cluster list entries kept in LDS
     int pid_lds;            // 1: particle class ids [K][P] live in LDS
     int pp_lds;             // 1: per-particle step scratch (sid, kv) lives in LDS
     int two_per_cu;         // 1: register-capped build so that two chains co-reside on a CU
@@ -107,7 +111,7 @@ struct FeatSelArgs {
 };
 
 size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T);
-hipError_t pmdi_launch_sweep(const SweepArgs &a, int n_chains, int T, hipStream_t stream);
+hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t stream);
 hipError_t pmdi_launch_cluster_add(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logprob(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_t stream);

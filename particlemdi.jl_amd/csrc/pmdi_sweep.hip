@@ -25,10 +25,24 @@ using namespace pmdi_dev;
 
 namespace {
 
+// LDS arrays are held as 32-bit address-space-3 pointers: half the registers of generic
+// pointers and guaranteed ds_* instructions.
+typedef __attribute__((address_space(3))) int *lint;
+typedef __attribute__((address_space(3))) unsigned *lu32;
+typedef __attribute__((address_space(3))) double *ldbl;
+typedef __attribute__((address_space(3))) unsigned long long *lu64;
+typedef __attribute__((address_space(3))) long long *li64;
+typedef __attribute__((address_space(3))) unsigned char *lu8;
+
+// explicit LDS -> generic pointer conversion (after inlining the compiler still sees the
+// address space and emits ds_* instructions)
+template <class Tp>
+__device__ __forceinline__ Tp *gen(__attribute__((address_space(3))) Tp *p) { return (Tp *)p; }
+
 // ---------------------------------------------------------------------------
 // Open-addressing hash table in LDS: key = cluster id (0 = empty), two payload words.
 struct HT {
-    int *key, *a, *b;
+    lint key, a, b;
     unsigned mask;
 };
 
@@ -40,10 +54,10 @@ __device__ __forceinline__ int ht_insert(const HT &h, int id, bool &won, int max
     unsigned s = ht_hash(id) & h.mask;
     won = false;
     for (int pr = 0; pr < maxprobe; ++pr) {
-        const int k = __hip_atomic_load(&h.key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int k = __hip_atomic_load(gen(&h.key[s]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (k == id) return (int)s;
         if (k == 0) {
-            const int old = atomicCAS(&h.key[s], 0, id);
+            const int old = atomicCAS(gen(&h.key[s]), 0, id);
             if (old == 0) { won = true; return (int)s; }
             if (old == id) return (int)s;
         }
@@ -62,6 +76,16 @@ __device__ __forceinline__ int ht_find(const HT &h, int id)
     return 0;
 }
 
+// Barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
+// load and store of the wave (s_waitcnt vmcnt(0)); inside a fast-path step, global data written
+// by one lane is read by other lanes in the NEXT step at the earliest, so only the step's last
+// barrier needs that -- the others let global loads (e.g. the prefetched observation row) and
+// stores stay in flight.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
@@ -75,67 +99,69 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
     const int Dp = (a.Dmax + 15) & ~15;
-    c.xs = take((size_t)a.Dmax * 8);
-    c.pis = take((size_t)a.K * a.N * 8);
-    c.lw = take((size_t)a.P * 8);
-    c.term = take((size_t)a.terms_cap * 8);
-    c.lpl = take((size_t)a.item_cap * 8);
-    c.cdf = take((size_t)(a.item_cap + a.item_cap / 2 + 2) * 8);
+    // ---- fixed-size tables: compile-time offsets ----
     c.scan = take(16 * 8);
     c.red = take(32 * 8);
-    c.pid = take(a.pid_lds ? (size_t)a.K * a.P * 4 : 0);
-    c.sid = take(a.pp_lds ? (size_t)a.P * 4 : 0);
-    c.kv = take(a.pp_lds ? (size_t)a.P * 4 : 0);
-    c.lead_of = take((size_t)(a.P + 1) * 4);
-    c.slot_of = take((size_t)(a.P + 1) * 4);
-    c.cl_lead = take((size_t)a.K * a.cls_lds * 4);
-    c.cl_val = take((size_t)a.K * a.cls_lds * 4);
-    c.need = take((size_t)a.item_cap * 4);
-    c.need_slot = take((size_t)a.item_cap * 4);
-    c.item_id = take((size_t)a.item_cap * 4);
-    c.dl = take((size_t)3 * a.dl_lds * 4);
-    c.dl_slot = take((size_t)a.dl_lds * 4);
-    c.h1k = take((size_t)a.ht_size * 4);
-    c.h1a = take((size_t)a.ht_size * 4);
-    c.h2k = take((size_t)a.ht_size * 4);
-    c.h2a = take((size_t)a.ht_size * 4);
-    c.h2b = take((size_t)a.ht_size * 4);
-    c.ktab_minp = take((size_t)a.item_cap * 4);
-    c.ktab_val = take((size_t)a.item_cap * 4);
-    c.klist = take((size_t)a.item_cap * 4);
-    c.kl_v = take((size_t)a.item_cap * 4);
-    c.kl_key = take((size_t)a.item_cap * 4);
-    c.fl_p = take((size_t)a.ht_size * 4);
-    c.fl_slot = take((size_t)a.ht_size * 4);
-    c.fl_nnew = take((size_t)a.ht_size * 4);
-    c.fl_tgt = take((size_t)a.ht_size * 4);
-    c.bm_fresh = take((size_t)((a.P >> 5) + 1) * 4);
-    c.bm_clone = take((size_t)((a.P >> 5) + 1) * 4);
+    c.misc = take(16 * 4);
+    c.ph = take(16 * 8);
     c.kmaxid = take(PMDI_KMAX_I * 4);
     c.kncls = take(PMDI_KMAX_I * 4);
     c.kcur = take(PMDI_KMAX_I * 4);
     c.knflag = take(PMDI_KMAX_I * 4);
     c.lab = take(256 * 3 * 4);
-    c.misc = take(16 * 4);
-    c.ph = take(16 * 8);
+    c.lpl = take((size_t)PMDI_ITEM_CAP * 8);
+    c.cdf = take((size_t)(PMDI_ITEM_CAP + PMDI_ITEM_CAP / 2 + 2) * 8);
+    c.need = take((size_t)PMDI_ITEM_CAP * 4);
+    c.need_slot = take((size_t)PMDI_ITEM_CAP * 4);
+    c.item_id = take((size_t)PMDI_ITEM_CAP * 4);
+    c.ktab_minp = take((size_t)PMDI_ITEM_CAP * 4);
+    c.ktab_val = take((size_t)PMDI_ITEM_CAP * 4);
+    c.klist = take((size_t)PMDI_ITEM_CAP * 4);
+    c.kl_v = take((size_t)PMDI_ITEM_CAP * 4);
+    c.kl_key = take((size_t)PMDI_ITEM_CAP * 4);
+    c.dl = take((size_t)3 * PMDI_DL_LDS * 4);
+    c.dl_slot = take((size_t)PMDI_DL_LDS * 4);
+    c.h1k = take((size_t)PMDI_HT_SIZE * 4);
+    c.h1a = take((size_t)PMDI_HT_SIZE * 4);
+    c.h2k = take((size_t)PMDI_HT_SIZE * 4);
+    c.h2a = take((size_t)PMDI_HT_SIZE * 4);
+    c.h2b = take((size_t)PMDI_HT_SIZE * 4);
+    c.fl_p = take((size_t)PMDI_HT_SIZE * 4);
+    c.fl_slot = take((size_t)PMDI_HT_SIZE * 4);
+    c.fl_nnew = take((size_t)PMDI_HT_SIZE * 4);
+    c.fl_tgt = take((size_t)PMDI_HT_SIZE * 4);
+    // ---- sizes that depend on the configuration ----
+    c.xs = take((size_t)a.Dmax * 8);
+    c.pis = take((size_t)a.K * a.N * 8);
+    c.term = take((size_t)a.terms_cap * 8);
+    c.lw = take((size_t)a.P * 8);
+    c.pid = take(a.pid_lds ? (size_t)a.K * a.P * 4 : 0);
+    c.sid = take(a.pp_lds ? (size_t)a.P * 4 : 0);
+    c.kv = take(a.pp_lds ? (size_t)a.P * 4 : 0);
+    c.lead_of = take((size_t)(a.P + 1) * 4);
+    c.slot_of = take((size_t)(a.P + 1) * 4);
+    c.cl_lead = take((size_t)a.K * PMDI_CLS_LDS * 4);
+    c.cl_val = take((size_t)a.K * PMDI_CLS_LDS * 4);
+    c.bm_fresh = take((size_t)((a.P >> 6) + 1) * 8);
+    c.bm_clone = take((size_t)((a.P >> 6) + 1) * 8);
     c.fl = take((size_t)a.K * Dp);
     c.news = take((size_t)a.K * a.P);
     c.total = o;
 }
 
 struct Sh {
-    double *xs, *pis, *lw, *term, *lpl, *cdf, *red;
-    unsigned long long *scan;
-    int *pid, *sid, *kv, *lead_of, *slot_of, *cl_lead, *cl_val, *need, *need_slot, *item_id, *dl, *dl_slot;
+    ldbl xs, pis, lw, term, lpl, cdf, red;
+    lu64 scan;
+    lint pid, sid, kv, lead_of, slot_of, cl_lead, cl_val, need, need_slot, item_id, dl, dl_slot;
     HT h1, h2;
-    int *ktab_minp, *ktab_val, *klist, *kl_v, *kl_key, *fl_p, *fl_slot, *fl_nnew, *fl_tgt;
-    unsigned *bm_fresh, *bm_clone;
-    int *kmaxid, *kncls, *kcur, *knflag, *lab, *misc;
-    long long *ph;
-    unsigned char *fl, *news;
+    lint ktab_minp, ktab_val, klist, kl_v, kl_key, fl_p, fl_slot, fl_nnew, fl_tgt;
+    lu32 bm_fresh, bm_clone;
+    lint kmaxid, kncls, kcur, knflag, lab, misc;
+    li64 ph;
+    lu8 fl, news;
 };
 
-enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6 };
+enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6, M_FAIL = 7 };
 
 // class list of dataset k: slot r -> leader particle / class value.  The first cls_lds slots
 // live in LDS, the rest (burn-in only) in global memory.
@@ -162,7 +188,7 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
         const bool valid = p < P;
         const int cls = valid ? pidk[p] : 0;
         int cnt;
-        if (wave_group(cls, valid, cnt)) atomicMin(&sh.lead_of[cls], p);
+        if (wave_group(cls, valid, cnt)) atomicMin(gen(&sh.lead_of[cls]), p);
     }
     __syncthreads();
     unsigned long long carry = 0;
@@ -172,7 +198,7 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
         const int cls = valid ? pidk[p] : 0;
         const bool isl = valid && sh.lead_of[cls] == p;
         unsigned long long tot;
-        const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, sh.scan) + carry;
+        const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, gen(sh.scan)) + carry;
         if (isl) { cl.set((int)ex, p, cls); sh.slot_of[cls] = (int)ex; }
         carry += tot;
     }
@@ -181,82 +207,70 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
     return (int)carry;
 }
 
-// ---------------------------------------------------------------------------
-// WPS = minimum waves per SIMD the register allocation must allow (2 co-resident chains per CU
-// at T = 512 need 4)
-template <int T, int WPS>
-__global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chain = blockIdx.x;
-    const int K = a.K, N = a.N, P = a.P, cap = a.cap;
-    const long long n = a.n, n1 = a.n1;
-    const unsigned long long seed = a.seed + (unsigned long long)chain;
-    const unsigned iter = a.iter;
-    const int Dp = (a.Dmax + 15) & ~15;
-    const int H = a.ht_size;
+#define PMDI_PREAMBLE                                                                         \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                      \
+    const SweepArgs &a = *ap;                                                                  \
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                             \
+    const int chain = blockIdx.x;                                                              \
+    const int K = a.K, N = a.N, P = a.P, cap = a.cap;                                          \
+    const long long n = a.n, n1 = a.n1;                                                        \
+    const unsigned long long seed = a.seed + (unsigned long long)chain;                        \
+    const unsigned iter = a.iter;                                                              \
+    const int Dp = (a.Dmax + 15) & ~15;                                                        \
+    const int H = PMDI_HT_SIZE;                                                                   \
+    Sh sh;                                                                                     \
+    build_sh(a, smem, sh);                                                                     \
+    const int *s_in = a.s_in + (size_t)chain * K * n;                                          \
+    const int *order = a.order + (size_t)chain * n;                                            \
+    const double *Pi = a.Pi + (size_t)chain * K * N;                                           \
+    const double *logphi = a.logphi + (size_t)chain * a.npairs;                                \
+    const unsigned char *flags = a.flags ? a.flags + (size_t)chain * a.sumD : nullptr;         \
+    double *usc = a.uscratch + (size_t)chain * P;                                              \
+    int *pstar_raw = a.partstar + (size_t)chain * P;                                           \
+    (void)lane; (void)wave; (void)cap; (void)n1; (void)seed; (void)iter; (void)Dp; (void)H;    \
+    (void)s_in; (void)order; (void)Pi; (void)logphi; (void)flags; (void)usc; (void)pstar_raw
 
-    Sh sh;
-    {
+__device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem, Sh &sh)
+{
+    const int H = PMDI_HT_SIZE;
         Carve c;
         carve_lds(a, c);
-        sh.xs = (double *)(smem + c.xs); sh.pis = (double *)(smem + c.pis); sh.lw = (double *)(smem + c.lw);
-        sh.term = (double *)(smem + c.term); sh.lpl = (double *)(smem + c.lpl); sh.cdf = (double *)(smem + c.cdf);
-        sh.scan = (unsigned long long *)(smem + c.scan); sh.red = (double *)(smem + c.red);
-        sh.pid = (int *)(smem + c.pid); sh.sid = (int *)(smem + c.sid); sh.kv = (int *)(smem + c.kv);
-        sh.lead_of = (int *)(smem + c.lead_of); sh.slot_of = (int *)(smem + c.slot_of);
-        sh.cl_lead = (int *)(smem + c.cl_lead); sh.cl_val = (int *)(smem + c.cl_val);
-        sh.need = (int *)(smem + c.need); sh.need_slot = (int *)(smem + c.need_slot);
-        sh.item_id = (int *)(smem + c.item_id); sh.dl = (int *)(smem + c.dl); sh.dl_slot = (int *)(smem + c.dl_slot);
-        sh.h1.key = (int *)(smem + c.h1k); sh.h1.a = (int *)(smem + c.h1a); sh.h1.b = nullptr; sh.h1.mask = (unsigned)H - 1;
-        sh.h2.key = (int *)(smem + c.h2k); sh.h2.a = (int *)(smem + c.h2a); sh.h2.b = (int *)(smem + c.h2b); sh.h2.mask = (unsigned)H - 1;
-        sh.ktab_minp = (int *)(smem + c.ktab_minp); sh.ktab_val = (int *)(smem + c.ktab_val);
-        sh.klist = (int *)(smem + c.klist); sh.kl_v = (int *)(smem + c.kl_v); sh.kl_key = (int *)(smem + c.kl_key);
-        sh.fl_p = (int *)(smem + c.fl_p); sh.fl_slot = (int *)(smem + c.fl_slot); sh.fl_nnew = (int *)(smem + c.fl_nnew);
-        sh.fl_tgt = (int *)(smem + c.fl_tgt);
-        sh.bm_fresh = (unsigned *)(smem + c.bm_fresh); sh.bm_clone = (unsigned *)(smem + c.bm_clone);
-        sh.kmaxid = (int *)(smem + c.kmaxid); sh.kncls = (int *)(smem + c.kncls); sh.kcur = (int *)(smem + c.kcur); sh.knflag = (int *)(smem + c.knflag);
-        sh.lab = (int *)(smem + c.lab); sh.misc = (int *)(smem + c.misc); sh.ph = (long long *)(smem + c.ph);
-        sh.fl = smem + c.fl; sh.news = smem + c.news;
-    }
+        sh.xs = (ldbl)(smem + c.xs); sh.pis = (ldbl)(smem + c.pis); sh.lw = (ldbl)(smem + c.lw);
+        sh.term = (ldbl)(smem + c.term); sh.lpl = (ldbl)(smem + c.lpl); sh.cdf = (ldbl)(smem + c.cdf);
+        sh.scan = (lu64)(smem + c.scan); sh.red = (ldbl)(smem + c.red);
+        sh.pid = (lint)(smem + c.pid); sh.sid = (lint)(smem + c.sid); sh.kv = (lint)(smem + c.kv);
+        sh.lead_of = (lint)(smem + c.lead_of); sh.slot_of = (lint)(smem + c.slot_of);
+        sh.cl_lead = (lint)(smem + c.cl_lead); sh.cl_val = (lint)(smem + c.cl_val);
+        sh.need = (lint)(smem + c.need); sh.need_slot = (lint)(smem + c.need_slot);
+        sh.item_id = (lint)(smem + c.item_id); sh.dl = (lint)(smem + c.dl); sh.dl_slot = (lint)(smem + c.dl_slot);
+        sh.h1.key = (lint)(smem + c.h1k); sh.h1.a = (lint)(smem + c.h1a); sh.h1.b = (lint)smem; sh.h1.mask = (unsigned)H - 1;
+        sh.h2.key = (lint)(smem + c.h2k); sh.h2.a = (lint)(smem + c.h2a); sh.h2.b = (lint)(smem + c.h2b); sh.h2.mask = (unsigned)H - 1;
+        sh.ktab_minp = (lint)(smem + c.ktab_minp); sh.ktab_val = (lint)(smem + c.ktab_val);
+        sh.klist = (lint)(smem + c.klist); sh.kl_v = (lint)(smem + c.kl_v); sh.kl_key = (lint)(smem + c.kl_key);
+        sh.fl_p = (lint)(smem + c.fl_p); sh.fl_slot = (lint)(smem + c.fl_slot); sh.fl_nnew = (lint)(smem + c.fl_nnew);
+        sh.fl_tgt = (lint)(smem + c.fl_tgt);
+        sh.bm_fresh = (lu32)(smem + c.bm_fresh); sh.bm_clone = (lu32)(smem + c.bm_clone);
+        sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag);
+        sh.lab = (lint)(smem + c.lab); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph);
+        sh.fl = (lu8)(smem + c.fl); sh.news = (lu8)(smem + c.news);
+}
 
-    const int *s_in = a.s_in + (size_t)chain * K * n;
-    const int *order = a.order + (size_t)chain * n;
-    const double *Pi = a.Pi + (size_t)chain * K * N;
-    const double *logphi = a.logphi + (size_t)chain * a.npairs;
-    const unsigned char *flags = a.flags ? a.flags + (size_t)chain * a.sumD : nullptr;
-    double *usc = a.uscratch + (size_t)chain * P;
-    int *pstar_raw = a.partstar + (size_t)chain * P;
+// Cold paths live in __noinline__ functions (their loop-invariant values would otherwise be
+// hoisted across the whole sweep loop and spill the hot path's registers).  Each one rebuilds
+// its view of the arguments and of the LDS table.
 
-    long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
-    long long st_fast = 0, st_conv = 0, st_slow = 0;
-    long long ph_last = 0;
-    int ph_cur = 0;
-#define PH(i_)                                                                  \
-    do {                                                                        \
-        if (a.phase && tid == 0) {                                              \
-            const long long t_ = clock64();                                     \
-            sh.ph[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_);         \
-        }                                                                       \
-    } while (0)
-    if (tid < 16) { sh.ph[tid] = 0; sh.misc[tid] = 0; }
-    long long ph_t0 = 0, ph_r0 = 0;
-    if (a.phase && tid == 0) { ph_last = clock64(); ph_t0 = ph_last; ph_r0 = wall_clock64(); }
-
-    for (int p = tid; p < P; p += T) sh.lw[p] = a.lw_init;
-    for (int c = tid; c <= P; c += T) { sh.lead_of[c] = PMDI_INF_I; sh.slot_of[c] = 0; }
-    for (int e = tid; e < H; e += T) { sh.h1.key[e] = 0; sh.h1.a[e] = 0; sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
-    for (int e = tid; e < a.item_cap; e += T) sh.ktab_minp[e] = PMDI_INF_I;
-    for (int e = tid; e <= (P >> 5); e += T) { sh.bm_fresh[e] = 0; sh.bm_clone[e] = 0; }
-
+// reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207)
+template <int T>
+__device__ __noinline__ void sweep_prefix(const SweepArgs *__restrict__ ap)
+{
+    PMDI_PREAMBLE;
     // ---- reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207) ----
     for (int k = 0; k < K; ++k) {
         const DsetDev &d = a.ds[k];
         const KS s = make_ks(d, chain);
         const int D = d.D;
-        int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
-        unsigned char *flk = sh.fl + (size_t)k * Dp;
+        int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
+        unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
         for (int idx = tid; idx <= cap; idx += T) { s.counts[idx] = 0; s.ncop[idx] = 0; s.firstc[idx] = PMDI_INF_I; }
         for (int idx = tid; idx < N * P; idx += T) { s.newid[idx] = 0; s.part[0][idx] = 1; }
         for (int p = tid; p < P; p += T) pidk[p] = 1;
@@ -267,8 +281,8 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
         // unique(s[order_obs[1:n1-1], k]) in first-appearance order (:192)
         for (long long j = tid; j < n1 - 1; j += T) {
             const int u = s_in[(size_t)k * n + order[j]];
-            atomicMin(&sh.lab[u], (int)j);
-            atomicAdd(&sh.lab[512 + u], 1);
+            atomicMin(gen(&sh.lab[u]), (int)j);
+            atomicAdd(gen(&sh.lab[512 + u]), 1);
         }
         __syncthreads();
         if (tid < N) {
@@ -341,267 +355,36 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
             int nf = 0;
             for (int q = 0; q < D; ++q) nf += flk[q];
             sh.knflag[k] = nf;
-            const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
+            const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
             cl.set(0, 0, 1);
         }
         __syncthreads();
     }
 
-    // ---- the sweep: src/pmdi.jl:209-342 ----
-    PH(1);
-    int failed = 0;
-    bool lw_uniform = true;     // every particle holds the same log-weight (then ESS == P exactly)
-    int i_next = order[n1 - 1];
-    for (long long pos = n1 - 1; pos < n && !failed; ++pos) {
-        const int i = i_next;
-        if (pos + 1 < n) i_next = order[pos + 1];
-        for (int k = 0; k < K && !failed; ++k) {
-            const DsetDev &d = a.ds[k];
-            const KS s = make_ks(d, chain);
-            const int D = d.D;
-            const int maxid = sh.kmaxid[k];
-            const int ncls = sh.kncls[k];
-            const int cur = sh.kcur[k];
-            int *part = s.part[cur];
-            int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
-            int *sidp = a.pp_lds ? sh.sid : s.sid;
-            int *kvp = a.pp_lds ? sh.kv : s.kv;
-            const unsigned char *flk = sh.fl + (size_t)k * Dp;
-            const double *pik = sh.pis + k * N;
-            const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
-            const int items = ncls * N;
-            const bool small = items <= a.item_cap;
-            if (ncls != 1) lw_uniform = false;
+}
 
-            PH(1);
-            // the observation row: issue the load now, land it in LDS after the needed-id pass
-            double xr = 0.0;
-            int xri = 0;
-            if (tid < D) {
-                if (d.kind == K_GAUSSIAN) xr = d.xf[(size_t)i * D + tid]; else xri = d.xi[(size_t)i * D + tid];
-            }
-            // slot_of is shared by the K datasets: rebuild it from this dataset's class list
-            for (int r = tid; r < ncls; r += T) sh.slot_of[cl.val(r)] = r;
-            if (tid == 0) sh.misc[M_OVF] = 0;
-
-            // -- A1: which clusters can a class leader reach?  (the reference evaluates every
-            // id 1..max at :218-220, but only these entries are ever read at :232)
-            if (small) {
-                for (int w = tid; w < items; w += T) {
-                    const int r = w / N, nn = w - r * N;
-                    const int id = part[nn * P + cl.lead(r)];
-                    sh.item_id[w] = id;
-                    bool won;
-                    const int slot = ht_insert(sh.h1, id, won, H);   // cannot fail: items <= ht_size/2
-                    if (won) {
-                        const int ps = atomicAdd(&sh.misc[M_NEED], 1);
-                        sh.need[ps] = id; sh.need_slot[ps] = slot; sh.h1.a[slot] = ps;
-                    }
-                }
-            }
-            if (tid < D) {
-                if (d.kind == K_GAUSSIAN) sh.xs[tid] = xr; else ((int *)sh.xs)[tid] = xri;
-            }
-            for (int q = T + tid; q < D; q += T) {
-                if (d.kind == K_GAUSSIAN) sh.xs[q] = d.xf[(size_t)i * D + q]; else ((int *)sh.xs)[q] = d.xi[(size_t)i * D + q];
-            }
-            __syncthreads();
-            const int nneed = small ? sh.misc[M_NEED] : maxid;
-            const int nflag = sh.knflag[k];
-
-            // -- A2/A3: log-predictive of the needed clusters.  Lanes = (cluster, feature) for
-            // the per-feature terms, then one lane per cluster adds them in feature order
-            // (bit-identical to the sequential loops of calc_logprob).
-            {
-                const int RS = 2 * D + 1, D1 = D + 1;
-                int CH = a.terms_cap / RS;
-                if (CH < 1) CH = 1;
-                for (int j0 = 0; j0 < nneed; j0 += CH) {
-                    const int nid = min(CH, nneed - j0);
-                    PH(2);
-                    for (int it = tid; it < nid * D1; it += T) {
-                        const int il = it / D1, q = it - il * D1;
-                        const int id = small ? sh.need[j0 + il] : 1 + j0 + il;
-                        const int cn = s.cn[id];
-                        if (q == D) {   // the per-cluster prefix: gaussian_cluster.jl:38-40
-                            if (d.kind == K_GAUSSIAN) sh.term[il * RS + 2 * D] = (double)nflag * d.gtab[cn];
-                            continue;
-                        }
-                        if (!flk[q]) continue;
-                        double ta = 0.0, tb = 0.0;
-                        if (d.kind == K_GAUSSIAN) {
-                            gauss_terms(sh.xs[q], (double)cn, gauss_ml(cn, s.sb[(size_t)id * D + q]), ta, tb);
-                        } else if (d.kind == K_CATEGORICAL) {
-                            const int x = ((const int *)sh.xs)[q];
-                            ta = d.lhtab[d.maxcol[q] + 2 * cn];                 // log(nlevels_q + n)
-                            const int c = s.cnt[((size_t)id * D + q) * d.L + (x - 1)];
-                            tb = (cn == 0) ? d.lhtab[1] : d.lhtab[2 * c + 1];   // log(0.5 + counts)
-                        } else {
-                            const int x = ((const int *)sh.xs)[q];
-                            ta = negbin_term(d.lgtab, cn, x, s.nbs[(size_t)id * D + q]);
-                        }
-                        sh.term[il * RS + 2 * q] = ta;
-                        sh.term[il * RS + 2 * q + 1] = tb;
-                    }
-                    __syncthreads();
-                    PH(3);
-                    for (int il = tid; il < nid; il += T) {
-                        const double *t = sh.term + il * RS;
-                        double out;
-                        if (d.kind == K_GAUSSIAN) {
-                            out = t[2 * D];
-                            if (nflag == D) {   // all features on: fetch 8 features' terms, then add in order
-                                for (int q0 = 0; q0 < D; q0 += 8) {
-                                    double ra[8], rb[8];
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u) {
-                                        const int q = min(q0 + u, D - 1);
-                                        ra[u] = t[2 * q]; rb[u] = t[2 * q + 1];
-                                    }
-#pragma unroll
-                                    for (int u = 0; u < 8; ++u)
-                                        if (q0 + u < D) { out += ra[u]; out -= rb[u]; }
-                                }
-                            } else {
-                                for (int q = 0; q < D; ++q)
-                                    if (flk[q]) { out += t[2 * q]; out -= t[2 * q + 1]; }
-                            }
-                        } else if (d.kind == K_CATEGORICAL) {
-                            double acc = 0.0;                                  // categorical_cluster.jl:30
-                            for (int q = 0; q < D; ++q) if (flk[q]) acc += t[2 * q];
-                            out = -acc;
-                            for (int q = 0; q < D; ++q) if (flk[q]) out += t[2 * q + 1];
-                        } else {
-                            out = 0.0;                                         // negbinom_cluster.jl:25
-                            for (int q = 0; q < D; ++q) if (flk[q]) out += t[2 * q];
-                        }
-                        if (small) sh.lpl[j0 + il] = out; else s.lp[1 + j0 + il] = out;
-                    }
-                    __syncthreads();
-                }
-            }
-
-            // -- B: mutation CDF per particle class (:231-248): lanes = (class, label) inside a
-            // wave; max / cumsum / normalise by shuffles.  The cumsum follows Julia's
-            // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
-            PH(4);
-            double *cdfp = small ? sh.cdf : s.cdf;
-            {
-                const int G = 64 / N;
-                const int g = lane / N, nn = lane - g * N;
-                const int gbase = (g < G) ? g * N : 0;
-                double *wv = sh.term + wave * 128;      // this wave's exchange area (terms are dead here)
-                for (int r0 = 0; r0 < ncls; r0 += (T / 64) * G) {
-                    if (r0 + wave * G >= ncls) break;          // wave-uniform: nothing left for this wave
-                    const int r = r0 + wave * G + g;
-                    const bool valid = (g < G) && (r < ncls);
-                    double v = 0.0;
-                    if (valid) {
-                        if (small) v = sh.lpl[sh.h1.a[ht_find(sh.h1, sh.item_id[r * N + nn])]];
-                        else v = s.lp[part[nn * P + cl.lead(r)]];
-                    }
-                    wv[lane] = v;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    double m = v;
-                    for (int j = 0; j < N; ++j) {
-                        const double t = wv[gbase + j];
-                        m = (t > m) ? t : m;
-                    }
-                    double e = v - m;
-                    e = exp(e);
-                    e = e * pik[nn];
-                    wv[64 + lane] = e;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const double e0 = wv[64 + gbase];
-                    double s_ = 0.0;
-                    for (int j = 1; j < N; ++j) {
-                        const double t = wv[64 + gbase + j];
-                        if (j <= nn) s_ = (j == 1) ? t : s_ + t;
-                    }
-                    const double c = (nn == 0) ? e : e0 + s_;
-                    __builtin_amdgcn_wave_barrier();
-                    wv[lane] = c;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    const double fN = wv[gbase + N - 1];
-                    if (valid) {
-                        cdfp[(size_t)r * (N + 1) + nn] = c / fN;
-                        if (nn == N - 1) cdfp[(size_t)r * (N + 1) + N] = log(fN) + m;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            __syncthreads();
-
-            // -- C..F: allocation draw (:251-265), class ids (:266-272), copy-on-write update of the
-            // chosen clusters (:275-310).  Fast path (the step's tables fit LDS): classes come from a
-            // (class, label) key table, ranks "in particle order" from LDS bitmaps + popcounts, no
-            // block-wide scans.  Fallback (burn-in): per-particle keys, ballot scans, global tables.
-            PH(5);
-            if (small) {
-                for (int j = tid; j < nneed; j += T) { const int sl = sh.need_slot[j]; sh.h1.key[sl] = 0; sh.h1.a[sl] = 0; }
-                if (tid == 0) sh.misc[M_NEED] = 0;
-            }
-            bool fast = small;
-            bool converted = false;
-            int nd = 0, nclone = 0, new_ncls = 0;
-            if (fast) {
-                for (int pb = 0; pb < P; pb += T) {
-                    const int p = pb + tid;
-                    const bool valid = p < P;
-                    int ns = 0, c = 0, kidx = 0;
-                    if (valid) {
-                        const int r = sh.slot_of[pidk[p]];
-                        const double *row = sh.cdf + (size_t)r * (N + 1);
-                        if (p != 0) {
-                            const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
-                            // first label whose CDF exceeds u (:252-260); the CDF is non-decreasing, so
-                            // that is the number of leading entries that do not exceed u
-                            for (int t = 0; t < N - 1; ++t) ns += (row[t] > u) ? 0 : 1;
-                        } else {
-                            ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
-                        }
-                        sh.lw[p] += row[N];
-                        c = part[ns * P + p];                        // sstar_id (:264)
-                        kidx = r * N + ns;
-                        sidp[p] = kidx;
-                        sh.news[k * P + p] = (unsigned char)ns;
-                        s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
-                    }
-                    const unsigned long long vmask = __ballot(valid);
-                    const int k0 = __shfl(kidx, 0), c0 = __shfl(c, 0);
-                    int slot = -1;
-                    if (__all(!valid || (kidx == k0 && c == c0))) {     // the whole wave agrees: one lane speaks
-                        if (lane == 0 && valid) {
-                            atomicMin(&sh.ktab_minp[k0], p);
-                            bool won;
-                            slot = ht_insert(sh.h2, c0, won, 48);
-                            if (slot < 0) sh.misc[M_OVF] = 1;
-                            else { atomicAdd(&sh.h2.a[slot], __popcll(vmask)); atomicMin(&sh.h2.b[slot], p); }
-                        }
-                        slot = __shfl(slot, 0);
-                    } else {
-                        if (valid) atomicMin(&sh.ktab_minp[kidx], p);
-                        int cnt;
-                        const int lead = wave_group_lead(c, valid, cnt);
-                        if (valid && lead == lane) {
-                            bool won;
-                            slot = ht_insert(sh.h2, c, won, 48);
-                            if (slot < 0) sh.misc[M_OVF] = 1;
-                            else { atomicAdd(&sh.h2.a[slot], cnt); atomicMin(&sh.h2.b[slot], p); }
-                        }
-                        slot = __shfl(slot, lead);
-                    }
-                    if (valid) kvp[p] = slot;
-                }
-                __syncthreads();
-                if (sh.misc[M_OVF]) {
-                    // too many distinct chosen clusters for the LDS census: hand this step to the
-                    // fallback (per-particle keys, per-id tables in global memory)
-                    fast = false;
-                    converted = true;
+// One (observation, dataset) step on the fallback path: per-particle class keys, ballot scans,
+// per-id tables in global memory.  `converted`: the fast path already drew the allocations but
+// its LDS census overflowed.  Results (clones, classes, pool overflow) go back through sh.misc.
+template <int T>
+__device__ __noinline__ void sweep_slow(const SweepArgs *__restrict__ ap, int k, int i, long long pos, bool small,
+                                        bool converted, int maxid, int ncls)
+{
+    PMDI_PREAMBLE;
+    const DsetDev &d = a.ds[k];
+    const KS s = make_ks(d, chain);
+    const int D = d.D;
+    int *part = s.part[sh.kcur[k]];
+    int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
+    int *sidp = a.pp_lds ? gen(sh.sid) : s.sid;
+    int *kvp = a.pp_lds ? gen(sh.kv) : s.kv;
+    const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
+    const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
+    const int items = ncls * N;
+    double *cdfp = small ? gen(sh.cdf) : s.cdf;
+    int nd = 0, nclone = 0, new_ncls = 0, failed = 0;
+    (void)items;
+    if (converted) {
                     for (int w = tid; w < items; w += T) sh.ktab_minp[w] = PMDI_INF_I;
                     for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
                     for (int pb = 0; pb < P; pb += T) {
@@ -622,127 +405,9 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                         if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
                         if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
                     }
-                    __syncthreads();
-                }
-            }
-            if (fast) {
-                // -- D'1: the touched (class, label) keys and the first particle of every chosen cluster
-                PH(6);
-                for (int w = tid; w < items; w += T) {
-                    const int mp = sh.ktab_minp[w];
-                    if (mp != PMDI_INF_I) {
-                        const int r = w / N, ns = w - r * N;
-                        const int key = (cl.val(r) - 1) * N + ns;
-                        const int v = (a.q1 == 1) ? 0 : s.newid[key];          // (:266)
-                        const int j = atomicAdd(&sh.misc[M_NK], 1);
-                        sh.klist[j] = w; sh.kl_v[j] = v; sh.kl_key[j] = key;
-                        if (v <= 0) atomicOr(&sh.bm_fresh[mp >> 5], 1u << (mp & 31));
-                    }
-                }
-                for (int pb = 0; pb < P; pb += T) {
-                    const int p = pb + tid;
-                    if (p < P) {
-                        const int slot = kvp[p];
-                        if (sh.h2.b[slot] == p) {
-                            const int c = sh.h2.key[slot];
-                            const bool needs = sh.h2.a[slot] != s.counts[c];       // ncopies == counts ? (:286)
-                            const int j = atomicAdd(&sh.misc[M_NF], 1);
-                            sh.fl_p[j] = needs ? (p | 0x40000000) : p;
-                            sh.fl_slot[j] = slot;
-                            sh.fl_nnew[j] = s.cn[c] + 1;
-                            if (needs) atomicOr(&sh.bm_clone[p >> 5], 1u << (p & 31));
-                        }
-                    }
-                }
-                __syncthreads();
-                // -- D'2: ranks in particle order by popcounts below the particle's bit
-                PH(7);
-                const int nk = sh.misc[M_NK], nf = sh.misc[M_NF];
-                if (wave == 0) {
-                    for (int j0 = 0; j0 < nk; j0 += 64) {
-                        const int j = j0 + lane;
-                        if (j < nk) {
-                            const int w = sh.klist[j];
-                            int v = sh.kl_v[j];
-                            if (v <= 0) {                                           // curr_id += 1 (:267-269)
-                                v = 1 + popc_below(sh.bm_fresh, sh.ktab_minp[w]);
-                                if (a.q1 == 0) s.newid[sh.kl_key[j]] = v;
-                            }
-                            sh.kl_v[j] = v;
-                            sh.ktab_val[w] = v;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    // classes of the next step: one per distinct value, leader = lowest first particle
-                    for (int j0 = 0; j0 < nk; j0 += 64) {
-                        const int j = j0 + lane;
-                        if (j < nk) {
-                            const int v = sh.kl_v[j], mp = sh.ktab_minp[sh.klist[j]];
-                            int rep = 1;
-                            for (int j2 = 0; j2 < nk; ++j2)
-                                if (sh.kl_v[j2] == v && sh.ktab_minp[sh.klist[j2]] < mp) rep = 0;
-                            sh.kl_key[j] = rep;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    int nrep = 0;
-                    for (int j0 = 0; j0 < nk; j0 += 64) {
-                        const int j = j0 + lane;
-                        const bool rep = (j < nk) && sh.kl_key[j];
-                        if (rep) {
-                            const int mp = sh.ktab_minp[sh.klist[j]];
-                            int slot = 0;
-                            for (int j2 = 0; j2 < nk; ++j2)
-                                if (sh.kl_key[j2] && sh.ktab_minp[sh.klist[j2]] < mp) ++slot;
-                            cl.set(slot, mp, sh.kl_v[j]);
-                        }
-                        nrep += __popcll(__ballot(rep));
-                    }
-                    if (lane == 0) { sh.misc[M_NCLS] = nrep; sh.misc[M_NCLONE] = popc_below(sh.bm_clone, P); }
-                }
-                for (int j = tid; j < nf; j += T) {
-                    const int pp = sh.fl_p[j];
-                    const bool needs = (pp & 0x40000000) != 0;
-                    const int p = pp & 0x3fffffff;
-                    const int slot = sh.fl_slot[j];
-                    const int c = sh.h2.key[slot], ncp = sh.h2.a[slot];
-                    const int tgt = needs ? maxid + 1 + popc_below(sh.bm_clone, p) : c;    // (:290-292)
-                    sh.fl_p[j] = c;
-                    sh.fl_tgt[j] = tgt;
-                    if (tgt <= cap) {
-                        if (needs) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }             // (:293-294)
-                        s.cn[tgt] = sh.fl_nnew[j];
-                        sh.h2.a[slot] = tgt;                                                // chosen id -> updated id
-                    }
-                }
-                __syncthreads();
-                nd = nf;
-                nclone = sh.misc[M_NCLONE];
-                new_ncls = sh.misc[M_NCLS];
-                if (maxid + nclone > cap) { failed = 1; break; }
-                // -- E': apply (:301-308), sufficient statistics (:297,:300), table clean-up
-                PH(8);
-                for (int pb = 0; pb < P; pb += T) {
-                    const int p = pb + tid;
-                    if (p < P) {
-                        const int slot = kvp[p];
-                        const int c = sh.h2.key[slot], tgt = sh.h2.a[slot];
-                        if (tgt != c) part[(int)sh.news[k * P + p] * P + p] = tgt;
-                        pidk[p] = sh.ktab_val[sidp[p]];
-                    }
-                }
-                for (int it = tid; it < nd * D; it += T) {
-                    const int j = it / D, q = it - j * D;
-                    stats_update_one(d, s, flk[q], sh.xs, sh.fl_p[j], sh.fl_tgt[j], sh.fl_nnew[j], D, q);
-                }
-                for (int j = tid; j < nk; j += T) sh.ktab_minp[sh.klist[j]] = PMDI_INF_I;
-                for (int w = tid; w <= (P >> 5); w += T) { sh.bm_fresh[w] = 0; sh.bm_clone[w] = 0; }
-                __syncthreads();
-                for (int j = tid; j < nf; j += T) { const int sl = sh.fl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
-                if (tid == 0) { sh.misc[M_NK] = 0; sh.misc[M_NF] = 0; }
-            } else {
+        __syncthreads();
+    }
+    {
                 bool gcensus = converted;
                 if (!converted) {
                     for (int pb = 0; pb < P; pb += T) {
@@ -778,12 +443,11 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                             bool won;
                             const int slot = ht_insert(sh.h2, c, won, 48);
                             if (slot < 0) sh.misc[M_OVF] = 1;
-                            else { atomicAdd(&sh.h2.a[slot], cnt); atomicMin(&sh.h2.b[slot], p); }
+                            else { atomicAdd(gen(&sh.h2.a[slot]), cnt); atomicMin(gen(&sh.h2.b[slot]), p); }
                         }
                     }
                     __syncthreads();
                     gcensus = sh.misc[M_OVF] != 0;
-                    PH(13);
                     if (gcensus) {   // too many distinct clusters for the LDS table: per-id tables in global memory
                         for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
                         for (int pb = 0; pb < P; pb += T) {
@@ -799,7 +463,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
 
                 // -- D: ranks in particle order: fresh class keys (:266-269) and distinct chosen
                 // clusters, clone-or-in-place (:276-299)
-                PH(6);
                 unsigned long long carry = 0;
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
@@ -817,7 +480,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                         nc = fc && (ncp != s.counts[c]);
                     }
                     unsigned long long tot;
-                    const unsigned long long ex = block_flag_scan<T>(fk, fc, nc, tot, sh.scan) + carry;
+                    const unsigned long long ex = block_flag_scan<T>(fk, fc, nc, tot, gen(sh.scan)) + carry;
                     if (fk) s.newid[key] = (int)(ex & 0xfffffull) + 1;
                     if (fc) {
                         const int rc = (int)((ex >> 20) & 0xfffffull);
@@ -826,8 +489,8 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                             const int nnew = s.cn[c] + 1;
                             if (nc) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }   // (:293-294)
                             s.cn[tgt] = nnew;
-                            if (rc < a.dl_lds) {
-                                sh.dl[rc] = c; sh.dl[a.dl_lds + rc] = tgt; sh.dl[2 * a.dl_lds + rc] = nnew;
+                            if (rc < PMDI_DL_LDS) {
+                                sh.dl[rc] = c; sh.dl[PMDI_DL_LDS + rc] = tgt; sh.dl[2 * PMDI_DL_LDS + rc] = nnew;
                                 sh.dl_slot[rc] = slot;
                             } else {
                                 s.dl[rc] = c; s.dl[P + rc] = tgt; s.dl[2 * P + rc] = nnew;
@@ -841,10 +504,9 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                 nclone = (int)(carry >> 40);
                 if (maxid + nclone > cap) failed = 1;
                 __syncthreads();
-                if (failed) break;
+                if (failed) { if (tid == 0) sh.misc[M_FAIL] = 1; __syncthreads(); return; }
 
                 // -- E: apply: new class ids, remap cloned labels (:301-308)
-                PH(7);
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
                     const bool valid = p < P;
@@ -861,14 +523,13 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                         kvp[p] = key;
                     }
                     int cnt;
-                    if (wave_group(newcls, valid, cnt)) atomicMin(&sh.lead_of[newcls], p);
+                    if (wave_group(newcls, valid, cnt)) atomicMin(gen(&sh.lead_of[newcls]), p);
                 }
                 __syncthreads();
 
                 // -- F: class list for the next step; scratch clean-up; sufficient-statistic update
                 // of every distinct chosen cluster (deepcopy + cluster_add!, :297,:300):
                 // lanes = (cluster, feature)
-                PH(8);
                 {
                     unsigned long long ccarry = 0;
                     for (int pb = 0; pb < P; pb += T) {
@@ -877,17 +538,17 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                         const int cls = valid ? pidk[p] : 0;
                         const bool isl = valid && sh.lead_of[cls] == p;
                         unsigned long long tot;
-                        const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, sh.scan) + ccarry;
+                        const unsigned long long ex = block_flag_scan<T>(isl, false, false, tot, gen(sh.scan)) + ccarry;
                         if (isl) { cl.set((int)ex, p, cls); sh.slot_of[cls] = (int)ex; }
                         if (valid && a.q1 == 1) s.newid[kvp[p]] = 0;   // corrected mode: new_id per step
                         ccarry += tot;
                     }
                     if (gcensus) {
                         for (int j = tid; j < nd; j += T) {
-                            const int c = j < a.dl_lds ? sh.dl[j] : s.dl[j];
+                            const int c = j < PMDI_DL_LDS ? sh.dl[j] : s.dl[j];
                             s.ncop[c] = 0; s.firstc[c] = PMDI_INF_I;
                         }
-                    } else if (nd <= a.dl_lds) {
+                    } else if (nd <= PMDI_DL_LDS) {
                         for (int j = tid; j < nd; j += T) { const int sl = sh.dl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
                     } else {
                         for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
@@ -895,71 +556,28 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                     for (int it = tid; it < nd * D; it += T) {
                         const int j = it / D, q = it - j * D;
                         int src, dst, nnew;
-                        if (j < a.dl_lds) { src = sh.dl[j]; dst = sh.dl[a.dl_lds + j]; nnew = sh.dl[2 * a.dl_lds + j]; }
+                        if (j < PMDI_DL_LDS) { src = sh.dl[j]; dst = sh.dl[PMDI_DL_LDS + j]; nnew = sh.dl[2 * PMDI_DL_LDS + j]; }
                         else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
-                        stats_update_one(d, s, flk[q], sh.xs, src, dst, nnew, D, q);
+                        stats_update_one(d, s, flk[q], gen(sh.xs), src, dst, nnew, D, q);
                     }
                     new_ncls = (int)ccarry;
                     __syncthreads();
                     for (int r = tid; r < new_ncls; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
                 }
-            }
-            if (fast) ++st_fast; else if (converted) ++st_conv; else ++st_slow;
-            st_nops += maxid;                     // src/__pmdi.jl:187
-            st_sumcls += ncls;
-            st_nclones += nclone;
-            if (maxid + nclone > st_maxid) st_maxid = maxid + nclone;
-            if (tid == 0) { sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = new_ncls; }
-            __syncthreads();
-        }
-        if (failed) break;
+    }
+    if (tid == 0) { sh.misc[M_NCLONE] = nclone; sh.misc[M_NCLS] = new_ncls; }
+    __syncthreads();
+}
 
-        // -- Phi_upweight! (src/misc.jl:50-59)
-        PH(9);
-        if (K > 1) {
-            for (int p = tid; p < P; p += T) {
-                int pr = 0;
-                double w = sh.lw[p];
-                for (int k1 = 0; k1 < K - 1; ++k1)
-                    for (int k2 = k1 + 1; k2 < K; ++k2) {
-                        w += (sh.news[k1 * P + p] == sh.news[k2 * P + p]) ? logphi[pr] : 0.0;
-                        ++pr;
-                    }
-                sh.lw[p] = w;
-            }
-            lw_uniform = false;
-            __syncthreads();
-        }
-
-        // -- calc_ESS (src/misc.jl:15-25).  If every log-weight is the same number the sums are
-        // exact (P ones): ESS == P, no resampling; skip the exps.
-        if (!lw_uniform) {
-            const double l0 = sh.lw[0];
-            int same = 1;
-            for (int p = tid; p < P; p += T) same &= (sh.lw[p] == l0) ? 1 : 0;
-            lw_uniform = __syncthreads_and(same) != 0;
-        }
-        double ess = (double)P;
-        bool resample = false;
-        double mx = 0.0;
-        if (!lw_uniform) {
-            mx = -INFINITY;
-            for (int p = tid; p < P; p += T) { const double v = sh.lw[p]; mx = (v > mx) ? v : mx; }
-            mx = block_max<T>(mx, sh.red);
-            double sa = 0.0, sb2 = 0.0;
-            for (int p = tid; p < P; p += T) { const double w = exp(sh.lw[p] - mx); sa += w; sb2 += w * w; }
-            block_sum2<T>(sa, sb2, sh.red);
-            ess = (sa * sa) / sb2;
-            resample = ess <= 0.5 * (double)P;            // src/pmdi.jl:317
-        }
-
-        if (resample) {
+// draw_partstar (src/misc.jl:27-47), gather and compact renumbering (src/pmdi.jl:318-340)
+template <int T>
+__device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, long long pos, double mx)
+{
+    PMDI_PREAMBLE;
             // draw_partstar (src/misc.jl:27-47)
-            PH(10);
-            ++st_nres;
             const double u01 = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
             const double usl = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
-            double *wb = sh.term;
+            double *wb = gen(sh.term);
             for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
             __syncthreads();
             if (tid == 0) jl_cumsum_inplace(wb, P);               // cumsum (:29), Julia's pairwise order
@@ -983,7 +601,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
             int js = (int)(usl * (double)P);      // shuffle!, partstar[1]=1, sort! (:43-45)
             if (js >= P) js = P - 1;
             for (int p = tid; p < P; p += T) sh.lw[p] = 1.0;     // src/pmdi.jl:319
-            lw_uniform = true;
             __syncthreads();
 #define PMDI_ANC(pp) ((pp) == 0 ? 0 : ((pp) <= js ? pstar_raw[(pp) - 1] : pstar_raw[(pp)]))
             for (int k = 0; k < K; ++k) {                         // src/pmdi.jl:320-340
@@ -992,9 +609,9 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                 const int D = d.D;
                 const int cur = sh.kcur[k];
                 const int oldmax = sh.kmaxid[k];
-                int *pidk = a.pid_lds ? sh.pid + (size_t)k * P : s.pid;
-                int *sidp = a.pp_lds ? sh.sid : s.sid;
-                const ClsList cl{sh.cl_lead + k * a.cls_lds, sh.cl_val + k * a.cls_lds, s.clslead, s.clsval, a.cls_lds};
+                int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
+                int *sidp = a.pp_lds ? gen(sh.sid) : s.sid;
+                const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
                 const int *src = s.part[cur];
                 int *dst = s.part[cur ^ 1];
                 for (int idx = tid; idx < N * P; idx += T) {      // particle[:, partstar, k] (:322)
@@ -1013,7 +630,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                     const int id = 1 + b + tid;
                     const bool live = (id <= oldmax) && s.ncop[id];
                     unsigned long long tot;
-                    const unsigned long long ex = block_excl_scan<T>(live ? 1ull : 0ull, tot, sh.scan) + carry;
+                    const unsigned long long ex = block_excl_scan<T>(live ? 1ull : 0ull, tot, gen(sh.scan)) + carry;
                     if (live) s.firstc[id] = (int)ex + 1;
                     carry += tot;
                 }
@@ -1073,28 +690,21 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
                 __syncthreads();
             }
 #undef PMDI_ANC
-        }
+}
 
-        if (a.trace_on && tid == 0) {
-            double *tr = a.trace + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
-            tr[0] = ess;
-            tr[1] = resample ? 1.0 : 0.0;
-            for (int k = 0; k < K; ++k) { tr[2 + k] = (double)sh.kmaxid[k]; tr[2 + K + k] = (double)sh.kncls[k]; }
-        }
-    }
-
-    if (failed) {
-        if (tid == 0) a.err[chain] = -4;  // PMDI_E_POOL
-        return;
-    }
-
+// particle pick (src/pmdi.jl:345-350), s = sstar[p_star,:,:] (:373), counters
+template <int T>
+__device__ __noinline__ void sweep_final(const SweepArgs *__restrict__ ap, long long st_nops, long long st_nres,
+                                         long long st_nclones, long long st_maxid, long long st_sumcls,
+                                         long long st_fast, long long st_conv, long long st_slow)
+{
+    PMDI_PREAMBLE;
     // ---- particle pick (src/pmdi.jl:345-350) + s = sstar[p_star,:,:] (:373) ----
-    PH(11);
     {
         double mx = -INFINITY;
         for (int p = tid; p < P; p += T) { const double v = sh.lw[p]; mx = (v > mx) ? v : mx; }
-        mx = block_max<T>(mx, sh.red);
-        double *wb = sh.term;
+        mx = block_max<T>(mx, gen(sh.red));
+        double *wb = gen(sh.term);
         for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
         __syncthreads();
         if (tid == 0) {   // StatsBase.sample(::Weights): sequential sum and scan, as the oracle
@@ -1130,10 +740,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
             a.kstate[((size_t)chain * PMDI_KMAX_I + tid) * 2] = sh.kmaxid[tid];
             a.kstate[((size_t)chain * PMDI_KMAX_I + tid) * 2 + 1] = sh.kcur[tid];
         }
-        PH(12);
-        if (a.phase && tid == 0) { sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0; }
-        __syncthreads();
-        if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
         if (tid == 0) {
             a.pstar[chain] = pstar;
             long long *st = a.stats + (size_t)chain * 8;
@@ -1143,6 +749,524 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs a)
             a.err[chain] = 0;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// WPS = minimum waves per SIMD the register allocation must allow (2 co-resident chains per CU
+// at T = 512 need 4)
+template <int T, int WPS>
+__global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__restrict__ ap)
+{
+    PMDI_PREAMBLE;
+
+    long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
+    long long st_fast = 0, st_conv = 0, st_slow = 0;
+    long long ph_last = 0;
+    int ph_cur = 0;
+#define PH(i_)                                                                  \
+    do {                                                                        \
+        if (a.phase && tid == 0) {                                              \
+            const long long t_ = clock64();                                     \
+            sh.ph[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_);         \
+        }                                                                       \
+    } while (0)
+    if (tid < 16) { sh.ph[tid] = 0; sh.misc[tid] = 0; }
+    long long ph_t0 = 0, ph_r0 = 0;
+    if (a.phase && tid == 0) { ph_last = clock64(); ph_t0 = ph_last; ph_r0 = wall_clock64(); }
+
+    for (int p = tid; p < P; p += T) sh.lw[p] = a.lw_init;
+    for (int c = tid; c <= P; c += T) { sh.lead_of[c] = PMDI_INF_I; sh.slot_of[c] = 0; }
+    for (int e = tid; e < H; e += T) { sh.h1.key[e] = 0; sh.h1.a[e] = 0; sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
+    for (int e = tid; e < PMDI_ITEM_CAP; e += T) sh.ktab_minp[e] = PMDI_INF_I;
+    for (int e = tid; e < 2 * ((P >> 6) + 1); e += T) { sh.bm_fresh[e] = 0; sh.bm_clone[e] = 0; }
+
+    sweep_prefix<T>(ap);
+    // ---- the sweep: src/pmdi.jl:209-342 ----
+    PH(1);
+    int failed = 0;
+    bool lw_uniform = true;     // every particle holds the same log-weight (then ESS == P exactly)
+    int i_next = order[n1 - 1];
+    double nx = 0.0;          // register-staged observation row of the upcoming step
+    int nxi = 0;
+    {
+        const DsetDev &d0 = a.ds[0];
+        if (tid < d0.D) {
+            if (d0.kind == K_GAUSSIAN) nx = d0.xf[(size_t)i_next * d0.D + tid]; else nxi = d0.xi[(size_t)i_next * d0.D + tid];
+        }
+    }
+    for (long long pos = n1 - 1; pos < n && !failed; ++pos) {
+        const int i = i_next;
+        if (pos + 1 < n) i_next = order[pos + 1];
+        for (int k = 0; k < K && !failed; ++k) {
+            const DsetDev &d = a.ds[k];
+            const KS s = make_ks(d, chain);
+            const int D = d.D;
+            const int maxid = sh.kmaxid[k];
+            const int ncls = sh.kncls[k];
+            const int cur = sh.kcur[k];
+            int *part = s.part[cur];
+            int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
+            int *sidp = a.pp_lds ? gen(sh.sid) : s.sid;
+            int *kvp = a.pp_lds ? gen(sh.kv) : s.kv;
+            const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
+            const double *pik = gen(sh.pis + k * N);
+            const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
+            const int items = ncls * N;
+            const bool small = items <= PMDI_ITEM_CAP;
+            if (ncls != 1) lw_uniform = false;
+
+            PH(1);
+            // the observation row was fetched into registers during the previous step
+            if (tid < D) {
+                if (d.kind == K_GAUSSIAN) sh.xs[tid] = nx; else ((int *)sh.xs)[tid] = nxi;
+            }
+            // slot_of is shared by the K datasets: rebuild it from this dataset's class list
+            for (int r = tid; r < ncls; r += T) sh.slot_of[cl.val(r)] = r;
+            if (tid == 0) sh.misc[M_OVF] = 0;
+
+            // -- A1: which clusters can a class leader reach?  (the reference evaluates every
+            // id 1..max at :218-220, but only these entries are ever read at :232)
+            if (small) {
+                for (int w = tid; w < items; w += T) {
+                    const int r = w / N, nn = w - r * N;
+                    const int id = part[nn * P + cl.lead(r)];
+                    sh.item_id[w] = id;
+                    bool won;
+                    const int slot = ht_insert(sh.h1, id, won, H);   // cannot fail: items <= ht_size/2
+                    if (won) {
+                        const int ps = atomicAdd(gen(&sh.misc[M_NEED]), 1);
+                        sh.need[ps] = id; sh.need_slot[ps] = slot; sh.h1.a[slot] = ps;
+                    }
+                }
+            }
+            for (int q = T + tid; q < D; q += T) {
+                if (d.kind == K_GAUSSIAN) sh.xs[q] = d.xf[(size_t)i * D + q]; else ((int *)sh.xs)[q] = d.xi[(size_t)i * D + q];
+            }
+            if (small) lds_barrier(); else __syncthreads();
+            const int nneed = small ? sh.misc[M_NEED] : maxid;
+            const int nflag = sh.knflag[k];
+
+            // -- A2/A3: log-predictive of the needed clusters.  Lanes = (cluster, feature) for
+            // the per-feature terms, then one lane per cluster adds them in feature order
+            // (bit-identical to the sequential loops of calc_logprob).
+            {
+                const int RS = 2 * D + 1, D1 = D + 1;
+                int CH = a.terms_cap / RS;
+                if (CH < 1) CH = 1;
+                for (int j0 = 0; j0 < nneed; j0 += CH) {
+                    const int nid = min(CH, nneed - j0);
+                    PH(2);
+                    for (int it = tid; it < nid * D1; it += T) {
+                        const int il = it / D1, q = it - il * D1;
+                        const int id = small ? sh.need[j0 + il] : 1 + j0 + il;
+                        const int cn = s.cn[id];
+                        if (q == D) {   // the per-cluster prefix: gaussian_cluster.jl:38-40
+                            if (d.kind == K_GAUSSIAN) sh.term[il * RS + 2 * D] = (double)nflag * d.gtab[cn];
+                            continue;
+                        }
+                        if (!flk[q]) continue;
+                        double ta = 0.0, tb = 0.0;
+                        if (d.kind == K_GAUSSIAN) {
+                            gauss_terms(sh.xs[q], (double)cn, gauss_ml(cn, s.sb[(size_t)id * D + q]), ta, tb);
+                        } else if (d.kind == K_CATEGORICAL) {
+                            const int x = ((const int *)sh.xs)[q];
+                            ta = d.lhtab[d.maxcol[q] + 2 * cn];                 // log(nlevels_q + n)
+                            const int c = s.cnt[((size_t)id * D + q) * d.L + (x - 1)];
+                            tb = (cn == 0) ? d.lhtab[1] : d.lhtab[2 * c + 1];   // log(0.5 + counts)
+                        } else {
+                            const int x = ((const int *)sh.xs)[q];
+                            ta = negbin_term(d.lgtab, cn, x, s.nbs[(size_t)id * D + q]);
+                        }
+                        sh.term[il * RS + 2 * q] = ta;
+                        sh.term[il * RS + 2 * q + 1] = tb;
+                    }
+                    if (small) lds_barrier(); else __syncthreads();
+                    PH(3);
+                    for (int il = tid; il < nid; il += T) {
+                        const double *t = gen(sh.term + il * RS);
+                        double out;
+                        if (d.kind == K_GAUSSIAN) {
+                            out = t[2 * D];
+                            if (nflag == D) {   // all features on: fetch 8 features' terms, then add in order
+                                for (int q0 = 0; q0 < D; q0 += 8) {
+                                    double ra[8], rb[8];
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u) {
+                                        const int q = min(q0 + u, D - 1);
+                                        ra[u] = t[2 * q]; rb[u] = t[2 * q + 1];
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 8; ++u)
+                                        if (q0 + u < D) { out += ra[u]; out -= rb[u]; }
+                                }
+                            } else {
+                                for (int q = 0; q < D; ++q)
+                                    if (flk[q]) { out += t[2 * q]; out -= t[2 * q + 1]; }
+                            }
+                        } else if (d.kind == K_CATEGORICAL) {
+                            double acc = 0.0;                                  // categorical_cluster.jl:30
+                            for (int q = 0; q < D; ++q) if (flk[q]) acc += t[2 * q];
+                            out = -acc;
+                            for (int q = 0; q < D; ++q) if (flk[q]) out += t[2 * q + 1];
+                        } else {
+                            out = 0.0;                                         // negbinom_cluster.jl:25
+                            for (int q = 0; q < D; ++q) if (flk[q]) out += t[2 * q];
+                        }
+                        if (small) sh.lpl[j0 + il] = out; else s.lp[1 + j0 + il] = out;
+                    }
+                    if (small) lds_barrier(); else __syncthreads();
+                }
+            }
+
+            // -- B: mutation CDF per particle class (:231-248): lanes = (class, label) inside a
+            // wave; max / cumsum / normalise by shuffles.  The cumsum follows Julia's
+            // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
+            PH(4);
+            double *cdfp = small ? gen(sh.cdf) : s.cdf;
+            {
+                const int G = 64 / N;
+                const int g = lane / N, nn = lane - g * N;
+                const int gbase = (g < G) ? g * N : 0;
+                double *wv = gen(sh.term + wave * 128);      // this wave's exchange area (terms are dead here)
+                for (int r0 = 0; r0 < ncls; r0 += (T / 64) * G) {
+                    if (r0 + wave * G >= ncls) break;          // wave-uniform: nothing left for this wave
+                    const int r = r0 + wave * G + g;
+                    const bool valid = (g < G) && (r < ncls);
+                    double v = 0.0;
+                    if (valid) {
+                        if (small) v = sh.lpl[sh.h1.a[ht_find(sh.h1, sh.item_id[r * N + nn])]];
+                        else v = s.lp[part[nn * P + cl.lead(r)]];
+                    }
+                    wv[lane] = v;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    double m = v;
+                    {
+                        int j = 0;
+                        for (; j + 4 <= N; j += 4) {      // four LDS reads in flight
+                            const double t0 = wv[gbase + j], t1 = wv[gbase + j + 1], t2 = wv[gbase + j + 2], t3 = wv[gbase + j + 3];
+                            m = (t0 > m) ? t0 : m; m = (t1 > m) ? t1 : m; m = (t2 > m) ? t2 : m; m = (t3 > m) ? t3 : m;
+                        }
+                        for (; j < N; ++j) { const double t = wv[gbase + j]; m = (t > m) ? t : m; }
+                    }
+                    double e = v - m;
+                    e = exp(e);
+                    e = e * pik[nn];
+                    wv[64 + lane] = e;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const double e0 = wv[64 + gbase];
+                    double s_ = 0.0;
+                    {
+                        int j = 1;
+                        for (; j + 4 <= N; j += 4) {      // loads first, then the ordered adds
+                            const double t0 = wv[64 + gbase + j], t1 = wv[64 + gbase + j + 1],
+                                         t2 = wv[64 + gbase + j + 2], t3 = wv[64 + gbase + j + 3];
+                            if (j <= nn) s_ = (j == 1) ? t0 : s_ + t0;
+                            if (j + 1 <= nn) s_ = s_ + t1;
+                            if (j + 2 <= nn) s_ = s_ + t2;
+                            if (j + 3 <= nn) s_ = s_ + t3;
+                        }
+                        for (; j < N; ++j) { const double t = wv[64 + gbase + j]; if (j <= nn) s_ = (j == 1) ? t : s_ + t; }
+                    }
+                    const double c = (nn == 0) ? e : e0 + s_;
+                    __builtin_amdgcn_wave_barrier();
+                    wv[lane] = c;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const double fN = wv[gbase + N - 1];
+                    if (valid) {
+                        cdfp[(size_t)r * (N + 1) + nn] = c / fN;
+                        if (nn == N - 1) cdfp[(size_t)r * (N + 1) + N] = log(fN) + m;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (small) lds_barrier(); else __syncthreads();
+
+            // -- C..F: allocation draw (:251-265), class ids (:266-272), copy-on-write update of the
+            // chosen clusters (:275-310).  Fast path (the step's tables fit LDS): classes come from a
+            // (class, label) key table, ranks "in particle order" from LDS bitmaps + popcounts, no
+            // block-wide scans.  Fallback (burn-in): per-particle keys, ballot scans, global tables.
+            PH(5);
+            {   // prefetch the next step's observation row (dataset k+1 of this observation, or
+                // dataset 0 of the next one) into registers; it is consumed a whole step later
+                int kn = k + 1, in_ = i;
+                bool have = true;
+                if (kn == K) { kn = 0; in_ = i_next; have = pos + 1 < n; }
+                const DsetDev &dn = a.ds[kn];
+                if (have && tid < dn.D) {
+                    if (dn.kind == K_GAUSSIAN) nx = dn.xf[(size_t)in_ * dn.D + tid]; else nxi = dn.xi[(size_t)in_ * dn.D + tid];
+                }
+            }
+            if (small) {
+                for (int j = tid; j < nneed; j += T) { const int sl = sh.need_slot[j]; sh.h1.key[sl] = 0; sh.h1.a[sl] = 0; }
+                if (tid == 0) sh.misc[M_NEED] = 0;
+            }
+            bool fast = small;
+            bool converted = false;
+            int nd = 0, nclone = 0, new_ncls = 0;
+            if (fast) {
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    int ns = 0, c = 0, kidx = 0;
+                    if (valid) {
+                        const int r = sh.slot_of[pidk[p]];
+                        const double *row = gen(sh.cdf + (size_t)r * (N + 1));
+                        if (p != 0) {
+                            const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                            // first label whose CDF exceeds u (:252-260); the CDF is non-decreasing, so
+                            // that is the number of leading entries that do not exceed u
+                            int t = 0;
+                            for (; t + 4 <= N - 1; t += 4) {          // four LDS reads in flight
+                                const double a0 = row[t], a1 = row[t + 1], a2 = row[t + 2], a3 = row[t + 3];
+                                ns += ((a0 > u) ? 0 : 1) + ((a1 > u) ? 0 : 1) + ((a2 > u) ? 0 : 1) + ((a3 > u) ? 0 : 1);
+                            }
+                            for (; t < N - 1; ++t) ns += (row[t] > u) ? 0 : 1;
+                        } else {
+                            ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
+                        }
+                        sh.lw[p] += row[N];
+                        c = part[ns * P + p];                        // sstar_id (:264)
+                        kidx = r * N + ns;
+                        sidp[p] = kidx;
+                        sh.news[k * P + p] = (unsigned char)ns;
+                        s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
+                    }
+                    const unsigned long long vmask = __ballot(valid);
+                    const int k0 = __shfl(kidx, 0), c0 = __shfl(c, 0);
+                    int slot = -1;
+                    if (__all(!valid || (kidx == k0 && c == c0))) {     // the whole wave agrees: one lane speaks
+                        if (lane == 0 && valid) {
+                            atomicMin(gen(&sh.ktab_minp[k0]), p);
+                            bool won;
+                            slot = ht_insert(sh.h2, c0, won, 48);
+                            if (slot < 0) sh.misc[M_OVF] = 1;
+                            else { atomicAdd(gen(&sh.h2.a[slot]), __popcll(vmask)); atomicMin(gen(&sh.h2.b[slot]), p); }
+                        }
+                        slot = __shfl(slot, 0);
+                    } else {
+                        if (valid) atomicMin(gen(&sh.ktab_minp[kidx]), p);
+                        int cnt;
+                        const int lead = wave_group_lead(c, valid, cnt);
+                        if (valid && lead == lane) {
+                            bool won;
+                            slot = ht_insert(sh.h2, c, won, 48);
+                            if (slot < 0) sh.misc[M_OVF] = 1;
+                            else { atomicAdd(gen(&sh.h2.a[slot]), cnt); atomicMin(gen(&sh.h2.b[slot]), p); }
+                        }
+                        slot = __shfl(slot, lead);
+                    }
+                    if (valid) kvp[p] = slot;
+                }
+                lds_barrier();
+                if (sh.misc[M_OVF]) {
+                    // too many distinct chosen clusters for the LDS census: hand this step to the
+                    // fallback (per-particle keys, per-id tables in global memory)
+                    fast = false;
+                    converted = true;
+                    __syncthreads();
+                }
+            }
+            if (fast) {
+                // -- D'1: the touched (class, label) keys and the first particle of every chosen cluster
+                PH(6);
+                for (int w = tid; w < items; w += T) {
+                    const int mp = sh.ktab_minp[w];
+                    if (mp != PMDI_INF_I) {
+                        const int r = w / N, ns = w - r * N;
+                        const int key = (cl.val(r) - 1) * N + ns;
+                        const int v = (a.q1 == 1) ? 0 : s.newid[key];          // (:266)
+                        const int j = atomicAdd(gen(&sh.misc[M_NK]), 1);
+                        sh.klist[j] = w; sh.kl_v[j] = v; sh.kl_key[j] = key;
+                        if (v <= 0) atomicOr(gen(&sh.bm_fresh[mp >> 5]), 1u << (mp & 31));
+                    }
+                }
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    if (p < P) {
+                        const int slot = kvp[p];
+                        if (sh.h2.b[slot] == p) {
+                            const int c = sh.h2.key[slot];
+                            const bool needs = sh.h2.a[slot] != s.counts[c];       // ncopies == counts ? (:286)
+                            const int j = atomicAdd(gen(&sh.misc[M_NF]), 1);
+                            sh.fl_p[j] = needs ? (p | 0x40000000) : p;
+                            sh.fl_slot[j] = slot;
+                            sh.fl_nnew[j] = s.cn[c] + 1;
+                            if (needs) atomicOr(gen(&sh.bm_clone[p >> 5]), 1u << (p & 31));
+                        }
+                    }
+                }
+                lds_barrier();
+                // -- D'2: ranks in particle order by popcounts below the particle's bit
+                PH(7);
+                const int nk = sh.misc[M_NK], nf = sh.misc[M_NF];
+                if (wave == 0) {
+                    for (int j0 = 0; j0 < nk; j0 += 64) {
+                        const int j = j0 + lane;
+                        if (j < nk) {
+                            const int w = sh.klist[j];
+                            int v = sh.kl_v[j];
+                            if (v <= 0) {                                           // curr_id += 1 (:267-269)
+                                v = 1 + popc_below(gen(sh.bm_fresh), sh.ktab_minp[w]);
+                                if (a.q1 == 0) s.newid[sh.kl_key[j]] = v;
+                            }
+                            sh.kl_v[j] = v;
+                            sh.ktab_val[w] = v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    // classes of the next step: one per distinct value, leader = lowest first particle
+                    for (int j0 = 0; j0 < nk; j0 += 64) {
+                        const int j = j0 + lane;
+                        if (j < nk) {
+                            const int v = sh.kl_v[j], mp = sh.ktab_minp[sh.klist[j]];
+                            int rep = 1;
+                            for (int j2 = 0; j2 < nk; ++j2)
+                                if (sh.kl_v[j2] == v && sh.ktab_minp[sh.klist[j2]] < mp) rep = 0;
+                            sh.kl_key[j] = rep;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    int nrep = 0;
+                    for (int j0 = 0; j0 < nk; j0 += 64) {
+                        const int j = j0 + lane;
+                        const bool rep = (j < nk) && sh.kl_key[j];
+                        if (rep) {
+                            const int mp = sh.ktab_minp[sh.klist[j]];
+                            int slot = 0;
+                            for (int j2 = 0; j2 < nk; ++j2)
+                                if (sh.kl_key[j2] && sh.ktab_minp[sh.klist[j2]] < mp) ++slot;
+                            cl.set(slot, mp, sh.kl_v[j]);
+                        }
+                        nrep += __popcll(__ballot(rep));
+                    }
+                    if (lane == 0) { sh.misc[M_NCLS] = nrep; sh.misc[M_NCLONE] = popc_below(gen(sh.bm_clone), P); }
+                }
+                for (int j = tid; j < nf; j += T) {
+                    const int pp = sh.fl_p[j];
+                    const bool needs = (pp & 0x40000000) != 0;
+                    const int p = pp & 0x3fffffff;
+                    const int slot = sh.fl_slot[j];
+                    const int c = sh.h2.key[slot], ncp = sh.h2.a[slot];
+                    const int tgt = needs ? maxid + 1 + popc_below(gen(sh.bm_clone), p) : c;    // (:290-292)
+                    sh.fl_p[j] = c;
+                    sh.fl_tgt[j] = tgt;
+                    if (tgt <= cap) {
+                        if (needs) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }             // (:293-294)
+                        s.cn[tgt] = sh.fl_nnew[j];
+                        sh.h2.a[slot] = tgt;                                                // chosen id -> updated id
+                    }
+                }
+                lds_barrier();
+                nd = nf;
+                nclone = sh.misc[M_NCLONE];
+                new_ncls = sh.misc[M_NCLS];
+                if (maxid + nclone > cap) { failed = 1; break; }
+                // -- E': apply (:301-308), sufficient statistics (:297,:300), table clean-up
+                PH(8);
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    if (p < P) {
+                        const int slot = kvp[p];
+                        const int c = sh.h2.key[slot], tgt = sh.h2.a[slot];
+                        if (tgt != c) part[(int)sh.news[k * P + p] * P + p] = tgt;
+                        pidk[p] = sh.ktab_val[sidp[p]];
+                    }
+                }
+                for (int it = tid; it < nd * D; it += T) {
+                    const int j = it / D, q = it - j * D;
+                    stats_update_one(d, s, flk[q], gen(sh.xs), sh.fl_p[j], sh.fl_tgt[j], sh.fl_nnew[j], D, q);
+                }
+                for (int j = tid; j < nk; j += T) sh.ktab_minp[sh.klist[j]] = PMDI_INF_I;
+                for (int w = tid; w < 2 * ((P >> 6) + 1); w += T) { sh.bm_fresh[w] = 0; sh.bm_clone[w] = 0; }
+                lds_barrier();
+                for (int j = tid; j < nf; j += T) { const int sl = sh.fl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
+                if (tid == 0) { sh.misc[M_NK] = 0; sh.misc[M_NF] = 0; }
+            } else {
+                sweep_slow<T>(ap, k, i, pos, small, converted, maxid, ncls);
+                if (sh.misc[M_FAIL]) { failed = 1; break; }
+                nclone = sh.misc[M_NCLONE];
+                new_ncls = sh.misc[M_NCLS];
+            }
+            if (fast) ++st_fast; else if (converted) ++st_conv; else ++st_slow;
+            st_nops += maxid;                     // src/__pmdi.jl:187
+            st_sumcls += ncls;
+            st_nclones += nclone;
+            if (maxid + nclone > st_maxid) st_maxid = maxid + nclone;
+            if (tid == 0) { sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = new_ncls; }
+            __syncthreads();
+        }
+        if (failed) break;
+
+        // -- Phi_upweight! (src/misc.jl:50-59)
+        PH(9);
+        if (K > 1) {
+            for (int p = tid; p < P; p += T) {
+                int pr = 0;
+                double w = sh.lw[p];
+                for (int k1 = 0; k1 < K - 1; ++k1)
+                    for (int k2 = k1 + 1; k2 < K; ++k2) {
+                        w += (sh.news[k1 * P + p] == sh.news[k2 * P + p]) ? logphi[pr] : 0.0;
+                        ++pr;
+                    }
+                sh.lw[p] = w;
+            }
+            lw_uniform = false;
+            __syncthreads();
+        }
+
+        // -- calc_ESS (src/misc.jl:15-25).  If every log-weight is the same number the sums are
+        // exact (P ones): ESS == P, no resampling; skip the exps.
+        if (!lw_uniform) {
+            const double l0 = sh.lw[0];
+            int same = 1;
+            for (int p = tid; p < P; p += T) same &= (sh.lw[p] == l0) ? 1 : 0;
+            lw_uniform = __syncthreads_and(same) != 0;
+        }
+        double ess = (double)P;
+        bool resample = false;
+        double mx = 0.0;
+        if (!lw_uniform) {
+            mx = -INFINITY;
+            for (int p = tid; p < P; p += T) { const double v = sh.lw[p]; mx = (v > mx) ? v : mx; }
+            mx = block_max<T>(mx, gen(sh.red));
+            double sa = 0.0, sb2 = 0.0;
+            for (int p = tid; p < P; p += T) { const double w = exp(sh.lw[p] - mx); sa += w; sb2 += w * w; }
+            block_sum2<T>(sa, sb2, gen(sh.red));
+            ess = (sa * sa) / sb2;
+            resample = ess <= 0.5 * (double)P;            // src/pmdi.jl:317
+        }
+
+        if (resample) {
+            PH(10);
+            ++st_nres;
+            sweep_resample<T>(ap, pos, mx);
+            lw_uniform = true;
+        }
+
+        if (a.trace_on && tid == 0) {
+            double *tr = a.trace + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
+            tr[0] = ess;
+            tr[1] = resample ? 1.0 : 0.0;
+            for (int k = 0; k < K; ++k) { tr[2 + k] = (double)sh.kmaxid[k]; tr[2 + K + k] = (double)sh.kncls[k]; }
+        }
+    }
+
+    if (failed) {
+        if (tid == 0) a.err[chain] = -4;  // PMDI_E_POOL
+        return;
+    }
+
+    PH(11);
+    sweep_final<T>(ap, st_nops, st_nres, st_nclones, st_maxid, st_sumcls, st_fast, st_conv, st_slow);
+    PH(12);
+    if (a.phase && tid == 0) { sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0; }
+    __syncthreads();
+    if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
 }
 
 }  // namespace
@@ -1156,7 +1280,7 @@ size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T)
     return c.total;
 }
 
-hipError_t pmdi_launch_sweep(const SweepArgs &a, int n_chains, int T, hipStream_t stream)
+hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t stream)
 {
     const size_t lds = pmdi_sweep_lds_bytes(a, T);
     const bool two = a.two_per_cu != 0;
@@ -1167,7 +1291,12 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, int n_chains, int T, hipStream_
     else return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    void *args[] = {(void *)&a};
+    // the argument block lives in device memory (stream-ordered copy), the kernel gets a pointer:
+    // cold-path device functions then read what they need instead of holding it in registers
+    e = hipMemcpyAsync(d_args, &a, sizeof(SweepArgs), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    const SweepArgs *ap = d_args;
+    void *args[] = {(void *)&ap};
     e = hipLaunchKernel(fn, dim3(n_chains), dim3(T), args, lds, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
