@@ -90,7 +90,7 @@ __device__ __forceinline__ void lds_barrier()
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
         need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v,
-        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, kmaxid, kncls, kcur, knflag, lab, misc, ph,
+        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, lab, misc, ph,
         fl, news, total;
 };
 
@@ -109,6 +109,11 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.kcur = take(PMDI_KMAX_I * 4);
     c.knflag = take(PMDI_KMAX_I * 4);
     c.lab = take(256 * 3 * 4);
+    c.leaf_i1 = take(64 * 4);
+    c.leaf_n = take(64 * 4);
+    c.leaf_tot = take(64 * 8);
+    c.leaf_carry = take(64 * 8);
+    c.leaf_prog = take(256);
     c.lpl = take((size_t)PMDI_ITEM_CAP * 8);
     c.cdf = take((size_t)(PMDI_ITEM_CAP + PMDI_ITEM_CAP / 2 + 2) * 8);
     c.need = take((size_t)PMDI_ITEM_CAP * 4);
@@ -156,12 +161,15 @@ struct Sh {
     HT h1, h2;
     lint ktab_minp, ktab_val, klist, kl_v, kl_key, fl_p, fl_slot, fl_nnew, fl_tgt;
     lu32 bm_fresh, bm_clone;
+    lint leaf_i1, leaf_n;
+    ldbl leaf_tot, leaf_carry;
+    lu8 leaf_prog;
     lint kmaxid, kncls, kcur, knflag, lab, misc;
     li64 ph;
     lu8 fl, news;
 };
 
-enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6, M_FAIL = 7 };
+enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6, M_FAIL = 7, M_NLEAF = 8, M_NPROG = 9 };
 
 // class list of dataset k: slot r -> leader particle / class value.  The first cls_lds slots
 // live in LDS, the rest (burn-in only) in global memory.
@@ -250,6 +258,8 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
         sh.fl_p = (lint)(smem + c.fl_p); sh.fl_slot = (lint)(smem + c.fl_slot); sh.fl_nnew = (lint)(smem + c.fl_nnew);
         sh.fl_tgt = (lint)(smem + c.fl_tgt);
         sh.bm_fresh = (lu32)(smem + c.bm_fresh); sh.bm_clone = (lu32)(smem + c.bm_clone);
+        sh.leaf_i1 = (lint)(smem + c.leaf_i1); sh.leaf_n = (lint)(smem + c.leaf_n);
+        sh.leaf_tot = (ldbl)(smem + c.leaf_tot); sh.leaf_carry = (ldbl)(smem + c.leaf_carry); sh.leaf_prog = (lu8)(smem + c.leaf_prog);
         sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag);
         sh.lab = (lint)(smem + c.lab); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph);
         sh.fl = (lu8)(smem + c.fl); sh.news = (lu8)(smem + c.news);
@@ -264,6 +274,38 @@ template <int T>
 __device__ __noinline__ void sweep_prefix(const SweepArgs *__restrict__ ap)
 {
     PMDI_PREAMBLE;
+    if (tid == 0) {
+        // leaf decomposition of Julia's accumulate_pairwise! over [1, P) and its recursion as a
+        // post-order program (0 leaf, 3 descend left, 1 left done -> right, 2 node done), used by
+        // the resampling cumsum.  More than 64 leaves (P > ~4096): the serial form is used.
+        int nl = 0, np = 0, sp = 0;
+        int st_i1[24], st_n[24], st_stage[24];
+        bool ok = P > 1;
+        if (ok) { st_i1[0] = 1; st_n[0] = P - 1; st_stage[0] = 0; }
+        while (ok && sp >= 0) {
+            const int i1 = st_i1[sp], nn = st_n[sp];
+            if (nn < 128) {
+                if (nl >= 64 || np >= 255) { ok = false; break; }
+                sh.leaf_i1[nl] = i1; sh.leaf_n[nl] = nn; ++nl;
+                sh.leaf_prog[np++] = 0; --sp;
+            } else if (st_stage[sp] == 0) {
+                if (np >= 255) { ok = false; break; }
+                st_stage[sp] = 1; sh.leaf_prog[np++] = 3;
+                ++sp; st_i1[sp] = i1; st_n[sp] = nn >> 1; st_stage[sp] = 0;
+            } else if (st_stage[sp] == 1) {
+                if (np >= 255) { ok = false; break; }
+                st_stage[sp] = 2; sh.leaf_prog[np++] = 1;
+                const int n2 = nn >> 1;
+                ++sp; st_i1[sp] = i1 + n2; st_n[sp] = nn - n2; st_stage[sp] = 0;
+            } else {
+                if (np >= 255) { ok = false; break; }
+                sh.leaf_prog[np++] = 2; --sp;
+            }
+        }
+        sh.misc[M_NLEAF] = ok ? nl : 0;
+        sh.misc[M_NPROG] = ok ? np : 0;
+    }
+    __syncthreads();
     // ---- reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207) ----
     for (int k = 0; k < K; ++k) {
         const DsetDev &d = a.ds[k];
@@ -580,12 +622,64 @@ __device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, lo
             double *wb = gen(sh.term);
             for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
             __syncthreads();
-            if (tid == 0) jl_cumsum_inplace(wb, P);               // cumsum (:29), Julia's pairwise order
+            // cumsum (:29) in Julia's accumulate_pairwise! order, bit-exactly but in parallel: the
+            // recursion splits [1, P) into leaves of < 128 elements; a leaf's running sums s_ do not
+            // depend on its carry, so (1) one lane per leaf forms them, (2) one lane walks the tree
+            // to get every leaf's carry s = op(s, s_left), (3) c[i] = s + s_[i] for all i.
+            const int nleaf = sh.misc[M_NLEAF];
+            if (nleaf == 0 && tid == 0) jl_cumsum_inplace(wb, P);
+            if (tid < nleaf) {
+                const int i1 = sh.leaf_i1[tid], nn = sh.leaf_n[tid];
+                double s_ = wb[i1];
+                int i = i1 + 1;
+                for (; i + 4 <= i1 + nn; i += 4) {
+                    const double v0 = wb[i], v1 = wb[i + 1], v2 = wb[i + 2], v3 = wb[i + 3];
+                    s_ = s_ + v0; wb[i] = s_;
+                    s_ = s_ + v1; wb[i + 1] = s_;
+                    s_ = s_ + v2; wb[i + 2] = s_;
+                    s_ = s_ + v3; wb[i + 3] = s_;
+                }
+                for (; i < i1 + nn; ++i) { s_ = s_ + wb[i]; wb[i] = s_; }
+                sh.leaf_tot[tid] = s_;
+            }
             if (tid == T - 64) {                                  // u += 1/particles by repeated addition (:34)
                 double u = u01 / (double)P;
                 const double h = 1.0 / (double)P;
                 usc[0] = u;
-                for (int j = 1; j < P; ++j) { u += h; usc[j] = u; }
+                int j = 1;
+                for (; j + 8 <= P; j += 8) {
+                    const double u1 = u + h, u2 = u1 + h, u3 = u2 + h, u4 = u3 + h, u5 = u4 + h, u6 = u5 + h, u7 = u6 + h, u8 = u7 + h;
+                    usc[j] = u1; usc[j + 1] = u2; usc[j + 2] = u3; usc[j + 3] = u4;
+                    usc[j + 4] = u5; usc[j + 5] = u6; usc[j + 6] = u7; usc[j + 7] = u8;
+                    u = u8;
+                }
+                for (; j < P; ++j) { u += h; usc[j] = u; }
+            }
+            __syncthreads();
+            if (tid == 0 && nleaf > 0) {
+                // carries: replay the recursion over the leaf totals.  The decomposition (kernel
+                // start) stored the recursion as a post-order program: op 0 = leaf, op 1 = "right
+                // child starts: carry = carry_of_node + left total", op 2 = "node done: total =
+                // left + right".
+                double cs[24], lt[24];       // carry / left-total stacks
+                int sp = 0;
+                cs[0] = wb[0];
+                double ret = 0.0;
+                const int nprog = sh.misc[M_NPROG];
+                int leaf = 0;
+                for (int pc = 0; pc < nprog; ++pc) {
+                    const int op = sh.leaf_prog[pc];
+                    if (op == 0) { sh.leaf_carry[leaf] = cs[sp]; ret = sh.leaf_tot[leaf]; ++leaf; }
+                    else if (op == 3) { cs[sp + 1] = cs[sp]; ++sp; }                 // descend into a left child
+                    else if (op == 1) { lt[sp - 1] = ret; cs[sp] = cs[sp - 1] + ret; } // left done: right child's carry
+                    else { --sp; ret = lt[sp] + ret; }                                 // node done (s_ += right)
+                }
+            }
+            __syncthreads();
+            for (int lf = wave; lf < nleaf; lf += T / 64) {       // c[i] = op(s, s_)
+                const int i1 = sh.leaf_i1[lf], nn = sh.leaf_n[lf];
+                const double sc = sh.leaf_carry[lf];
+                for (int i = i1 + lane; i < i1 + nn; i += 64) wb[i] = sc + wb[i];
             }
             __syncthreads();
             const double last = wb[P - 1];
@@ -636,10 +730,28 @@ __device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, lo
                 }
                 const int newmax = (int)carry;
                 __syncthreads();
-                for (int idx = tid; idx < N * P; idx += T) {      // relabel + recount (:331-338)
-                    const int v = s.firstc[dst[idx]];
-                    dst[idx] = v;
-                    atomicAdd(&s.counts[v], 1);
+                // relabel + recount (:331-338); the histogram lives in LDS (the hash/list tables are
+                // idle here) when the renumbered ids fit, with wave-aggregated adds either way
+                lint hist = sh.h1.key;                            // 9 * PMDI_HT_SIZE contiguous ints
+                const bool lhist = newmax < 9 * PMDI_HT_SIZE;
+                if (lhist) for (int e = tid; e <= newmax; e += T) hist[e] = 0;
+                __syncthreads();
+                for (int base = 0; base < N * P; base += T) {
+                    const int idx = base + tid;
+                    const bool valid = idx < N * P;
+                    int v = 0;
+                    if (valid) { v = s.firstc[dst[idx]]; dst[idx] = v; }
+                    int cnt;
+                    if (wave_group(v, valid, cnt)) {
+                        if (lhist) atomicAdd(gen(&hist[v]), cnt); else atomicAdd(&s.counts[v], cnt);
+                    }
+                }
+                __syncthreads();
+                if (lhist) {
+                    for (int e = 1 + tid; e <= newmax; e += T) s.counts[e] = hist[e];
+                    __syncthreads();
+                    for (int e = tid; e < 9 * PMDI_HT_SIZE; e += T)       // tables back to empty (h2.b = INF)
+                        hist[e] = (e >= 4 * PMDI_HT_SIZE && e < 5 * PMDI_HT_SIZE) ? PMDI_INF_I : 0;
                 }
                 // clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending (:336):
                 // batches in ascending order, load -> barrier -> store

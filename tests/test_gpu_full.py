@@ -93,3 +93,37 @@ def test_pmdi_driver_csv(pkg, tmp_path):
     from collections import Counter
     top = Counter(st["s"][:, 0].tolist()).most_common(3)
     assert sum(v for _, v in top) > 120
+
+
+@pytest.mark.parametrize("cfg,scale,P", [("cfg3", 0.05, 256), ("cfg4", 0.03, 256), ("cfg5", 0.015, 512), ("HL", 0.03, 256)])
+def test_baseline_configs_reduced_vs_oracle(pkg, O, cfg, scale, P):
+    """Every BASELINE.json config (data types, K, N, D as specified; n and P reduced so that the
+    oracle finishes in seconds) run as a real Gibbs chain with host hyper-updates: device == oracle."""
+    from particlemdi_jl_amd import workloads
+    from particlemdi_jl_amd.hypers import HyperState
+    w = workloads.make(cfg, scale)
+    n, K, N = w["n"], w["K"], w["N"]
+    rng = np.random.default_rng(3)
+    hy = HyperState(n, N, K, rng)
+    sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=1, seed=17)
+    o = O.Oracle(w["data"], w["kinds"], N, P, seed=17)
+    order = np.arange(1, n + 1)
+    n1 = max(1, int(np.floor(0.25 * n)))
+    fast = 0
+    for it in range(1, 4):
+        rng.shuffle(order)
+        Pi = hy.step_pmdi_order()
+        rg = sw.sweep(it, hy.s[None], order[None], n1, Pi[None], hy.Phi[None])
+        ro = o.sweep(it, hy.s, order, n1, Pi, hy.Phi)
+        assert (rg["s"][0] == ro["s"]).all() and int(rg["p_star"][0]) == ro["p_star"], f"{cfg} iteration {it}"
+        assert np.allclose(rg["logweight"][0], ro["logweight"], rtol=1e-6)
+        for key in ("n_operations", "n_resamples", "n_clones", "sum_classes"):
+            assert rg["stats"][0][key] == ro["stats"][key]
+        fast += rg["stats"][0]["steps_fast"]
+        hy.s[:] = ro["s"]
+        hy.align_labels()
+    if cfg == "cfg5":      # feature selection (the calc_logmarginal path) on the 200-feature datasets
+        fl, pr = sw.feature_select(3, hy.s[None])
+        of, op = o.feature_select(3, hy.s)
+        assert (fl[0] == np.concatenate(of)).all()
+        assert np.allclose(pr[0], np.concatenate(op), rtol=1e-9)
