@@ -696,7 +696,10 @@ __device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, lo
             if (js >= P) js = P - 1;
             for (int p = tid; p < P; p += T) sh.lw[p] = 1.0;     // src/pmdi.jl:319
             __syncthreads();
-#define PMDI_ANC(pp) ((pp) == 0 ? 0 : ((pp) <= js ? pstar_raw[(pp) - 1] : pstar_raw[(pp)]))
+            // ancestor of every slot after the conditional-SMC fix-up (slot 0 keeps particle 0)
+            int *ancp = a.pp_lds ? gen(sh.kv) : make_ks(a.ds[0], chain).kv;
+            for (int p = tid; p < P; p += T) ancp[p] = (p == 0) ? 0 : (p <= js ? pstar_raw[p - 1] : pstar_raw[p]);
+            __syncthreads();
             for (int k = 0; k < K; ++k) {                         // src/pmdi.jl:320-340
                 const DsetDev &d = a.ds[k];
                 const KS s = make_ks(d, chain);
@@ -708,42 +711,63 @@ __device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, lo
                 const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
                 const int *src = s.part[cur];
                 int *dst = s.part[cur ^ 1];
-                for (int idx = tid; idx < N * P; idx += T) {      // particle[:, partstar, k] (:322)
-                    const int nn = idx / P, p = idx - nn * P;
-                    const int v = src[nn * P + PMDI_ANC(p)];
-                    dst[idx] = v;
-                    s.ncop[v] = 1;                                // live-id marks
-                }
-                for (int p = tid; p < P; p += T) sidp[p] = pidk[PMDI_ANC(p)];   // (:323)
+                // live marks, then old id -> new id, in LDS (the term buffer is idle) when the ids fit;
+                // otherwise the per-id scratch tables in global memory
+                const bool lm = oldmax + 1 <= 2 * a.terms_cap;
+                lint lmap = (lint)sh.term;
+                if (lm) for (int e = tid; e <= oldmax; e += T) lmap[e] = 0;
                 for (int id = 1 + tid; id <= oldmax; id += T) s.counts[id] = 0;   // (:326)
+                __syncthreads();
+                for (int pb = 0; pb < P; pb += T) {               // particle[:, partstar, k] (:322)
+                    const int p = pb + tid;
+                    if (p < P) {
+                        const int an = ancp[p];
+                        sidp[p] = pidk[an];                       // (:323)
+                        int nn = 0;
+                        for (; nn + 4 <= N; nn += 4) {            // four independent gathers in flight
+                            const int v0 = src[nn * P + an], v1 = src[(nn + 1) * P + an], v2 = src[(nn + 2) * P + an], v3 = src[(nn + 3) * P + an];
+                            dst[nn * P + p] = v0; dst[(nn + 1) * P + p] = v1; dst[(nn + 2) * P + p] = v2; dst[(nn + 3) * P + p] = v3;
+                            if (lm) { lmap[v0] = 1; lmap[v1] = 1; lmap[v2] = 1; lmap[v3] = 1; }
+                            else { s.ncop[v0] = 1; s.ncop[v1] = 1; s.ncop[v2] = 1; s.ncop[v3] = 1; }
+                        }
+                        for (; nn < N; ++nn) {
+                            const int v = src[nn * P + an];
+                            dst[nn * P + p] = v;
+                            if (lm) lmap[v] = 1; else s.ncop[v] = 1;
+                        }
+                    }
+                }
                 __syncthreads();
                 for (int p = tid; p < P; p += T) pidk[p] = sidp[p];
                 // sort(unique(particle)) ascending -> 1..U' (:329): scan of live marks
                 unsigned long long carry = 0;
                 for (int b = 0; b < oldmax; b += T) {
                     const int id = 1 + b + tid;
-                    const bool live = (id <= oldmax) && s.ncop[id];
+                    const bool live = (id <= oldmax) && (lm ? lmap[id] != 0 : s.ncop[id] != 0);
                     unsigned long long tot;
-                    const unsigned long long ex = block_excl_scan<T>(live ? 1ull : 0ull, tot, gen(sh.scan)) + carry;
-                    if (live) s.firstc[id] = (int)ex + 1;
+                    const unsigned long long ex = block_flag_scan<T>(live, false, false, tot, gen(sh.scan)) + carry;
+                    if (live) { if (lm) lmap[id] = (int)ex + 1; else s.firstc[id] = (int)ex + 1; }
                     carry += tot;
                 }
                 const int newmax = (int)carry;
-                __syncthreads();
                 // relabel + recount (:331-338); the histogram lives in LDS (the hash/list tables are
                 // idle here) when the renumbered ids fit, with wave-aggregated adds either way
                 lint hist = sh.h1.key;                            // 9 * PMDI_HT_SIZE contiguous ints
                 const bool lhist = newmax < 9 * PMDI_HT_SIZE;
                 if (lhist) for (int e = tid; e <= newmax; e += T) hist[e] = 0;
                 __syncthreads();
-                for (int base = 0; base < N * P; base += T) {
-                    const int idx = base + tid;
-                    const bool valid = idx < N * P;
-                    int v = 0;
-                    if (valid) { v = s.firstc[dst[idx]]; dst[idx] = v; }
-                    int cnt;
-                    if (wave_group(v, valid, cnt)) {
-                        if (lhist) atomicAdd(gen(&hist[v]), cnt); else atomicAdd(&s.counts[v], cnt);
+#define PMDI_NEWID(id_) (lm ? lmap[(id_)] : (s.ncop[(id_)] ? s.firstc[(id_)] : 0))
+                const bool moves = newmax > 0 && PMDI_NEWID(newmax) != newmax;   // else ids 1..newmax stay put
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    for (int nn = 0; nn < N; ++nn) {
+                        int v = 0;
+                        if (valid) { v = PMDI_NEWID(dst[nn * P + p]); dst[nn * P + p] = v; }
+                        int cnt;
+                        if (wave_group(v, valid, cnt)) {
+                            if (lhist) atomicAdd(gen(&hist[v]), cnt); else atomicAdd(&s.counts[v], cnt);
+                        }
                     }
                 }
                 __syncthreads();
@@ -753,55 +777,61 @@ __device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, lo
                     for (int e = tid; e < 9 * PMDI_HT_SIZE; e += T)       // tables back to empty (h2.b = INF)
                         hist[e] = (e >= 4 * PMDI_HT_SIZE && e < 5 * PMDI_HT_SIZE) ? PMDI_INF_I : 0;
                 }
-                // clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending (:336):
-                // batches in ascending order, load -> barrier -> store
-                for (int b = 0; b < oldmax; b += T) {
-                    const int id = 1 + b + tid;
-                    const bool mv = (id <= oldmax) && s.ncop[id] && s.firstc[id] != id;
-                    const int v = mv ? s.cn[id] : 0;
-                    __syncthreads();
-                    if (mv) s.cn[s.firstc[id]] = v;
+                if (moves) {
+                    // clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending (:336):
+                    // batches in ascending order, load -> barrier -> store
+                    for (int b = 0; b < oldmax; b += T) {
+                        const int id = 1 + b + tid;
+                        const int nid = (id <= oldmax) ? PMDI_NEWID(id) : 0;
+                        const bool mv = nid != 0 && nid != id;
+                        const int v = mv ? s.cn[id] : 0;
+                        __syncthreads();
+                        if (mv) s.cn[nid] = v;
+                    }
+                    const long long nitems = (long long)oldmax * D;
+                    if (d.kind == K_GAUSSIAN) {
+                        for (long long b = 0; b < nitems; b += T) {
+                            const long long it = b + tid;
+                            const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
+                            const int nid = (it < nitems) ? PMDI_NEWID(id) : 0;
+                            const bool mv = nid != 0 && nid != id;
+                            double2 sb = make_double2(0, 0);
+                            if (mv) sb = s.sb[(size_t)id * D + q];
+                            __syncthreads();
+                            if (mv) s.sb[(size_t)nid * D + q] = sb;
+                        }
+                    } else if (d.kind == K_CATEGORICAL) {
+                        const long long itemsL = nitems * d.L;
+                        const int DL = D * d.L;
+                        for (long long b = 0; b < itemsL; b += T) {
+                            const long long it = b + tid;
+                            const int id = 1 + (int)(it / DL), r = (int)(it - (long long)(id - 1) * DL);
+                            const int nid = (it < itemsL) ? PMDI_NEWID(id) : 0;
+                            const bool mv = nid != 0 && nid != id;
+                            const int v = mv ? s.cnt[(size_t)id * DL + r] : 0;
+                            __syncthreads();
+                            if (mv) s.cnt[(size_t)nid * DL + r] = v;
+                        }
+                    } else {
+                        for (long long b = 0; b < nitems; b += T) {
+                            const long long it = b + tid;
+                            const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
+                            const int nid = (it < nitems) ? PMDI_NEWID(id) : 0;
+                            const bool mv = nid != 0 && nid != id;
+                            const long long v = mv ? s.nbs[(size_t)id * D + q] : 0;
+                            __syncthreads();
+                            if (mv) s.nbs[(size_t)nid * D + q] = v;
+                        }
+                    }
                 }
-                const long long nitems = (long long)oldmax * D;
-                if (d.kind == K_GAUSSIAN) {
-                    for (long long b = 0; b < nitems; b += T) {
-                        const long long it = b + tid;
-                        const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
-                        const bool mv = (it < nitems) && s.ncop[id] && s.firstc[id] != id;
-                        double2 sb = make_double2(0, 0);
-                        if (mv) sb = s.sb[(size_t)id * D + q];
-                        __syncthreads();
-                        if (mv) s.sb[(size_t)s.firstc[id] * D + q] = sb;
-                    }
-                } else if (d.kind == K_CATEGORICAL) {
-                    const long long itemsL = nitems * d.L;
-                    const int DL = D * d.L;
-                    for (long long b = 0; b < itemsL; b += T) {
-                        const long long it = b + tid;
-                        const int id = 1 + (int)(it / DL), r = (int)(it - (long long)(id - 1) * DL);
-                        const bool mv = (it < itemsL) && s.ncop[id] && s.firstc[id] != id;
-                        const int v = mv ? s.cnt[(size_t)id * DL + r] : 0;
-                        __syncthreads();
-                        if (mv) s.cnt[(size_t)s.firstc[id] * DL + r] = v;
-                    }
-                } else {
-                    for (long long b = 0; b < nitems; b += T) {
-                        const long long it = b + tid;
-                        const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
-                        const bool mv = (it < nitems) && s.ncop[id] && s.firstc[id] != id;
-                        const long long v = mv ? s.nbs[(size_t)id * D + q] : 0;
-                        __syncthreads();
-                        if (mv) s.nbs[(size_t)s.firstc[id] * D + q] = v;
-                    }
-                }
+#undef PMDI_NEWID
                 __syncthreads();
-                for (int id = 1 + tid; id <= oldmax; id += T) { s.ncop[id] = 0; s.firstc[id] = PMDI_INF_I; }
+                if (!lm) for (int id = 1 + tid; id <= oldmax; id += T) { s.ncop[id] = 0; s.firstc[id] = PMDI_INF_I; }
                 __syncthreads();
                 const int nc2 = rebuild_classes<T>(pidk, cl, sh, P);
                 if (tid == 0) { sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1; }
                 __syncthreads();
             }
-#undef PMDI_ANC
 }
 
 // particle pick (src/pmdi.jl:345-350), s = sstar[p_star,:,:] (:373), counters
