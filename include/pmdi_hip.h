@@ -176,6 +176,10 @@ int pmdi_cluster_stats(pmdi_cluster_batch *cb, double *out, int64_t *stride);
 int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);
 
 /* sizes a caller needs to allocate outputs */
+/* Debug: shader cycles each chain's last sweep took (n_chains values); the library uses them to
+ * launch the heaviest chains first. */
+int pmdi_chain_costs(pmdi_handle *h, int64_t *out);
+
 int pmdi_sum_D(const pmdi_handle *h);
 int pmdi_block_threads(const pmdi_handle *h);   /* threads per chain workgroup */
 int64_t pmdi_lds_bytes(const pmdi_handle *h);    /* LDS bytes per chain workgroup */

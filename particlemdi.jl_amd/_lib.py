@@ -28,7 +28,7 @@ EXPORTS = [
     "pmdi_sweep_device", "pmdi_feature_select", "pmdi_export_state", "pmdi_clusters_new",
     "pmdi_clusters_free", "pmdi_cluster_add", "pmdi_calc_logprob", "pmdi_calc_logmarginal",
     "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L", "pmdi_phase_timers",
-    "pmdi_block_threads", "pmdi_lds_bytes",
+    "pmdi_block_threads", "pmdi_lds_bytes", "pmdi_chain_costs",
 ]
 
 
@@ -127,6 +127,8 @@ def lib():
     L.pmdi_block_threads.argtypes = [vp]
     L.pmdi_lds_bytes.restype = i64
     L.pmdi_lds_bytes.argtypes = [vp]
+    L.pmdi_chain_costs.restype = C.c_int
+    L.pmdi_chain_costs.argtypes = [vp, vp]
     L.pmdi_phase_timers.restype = C.c_int
     L.pmdi_phase_timers.argtypes = [vp, i32, vp]
     _lib = L
@@ -242,6 +244,11 @@ class Sweeper:
         mx = np.zeros(K, dtype=np.int64)
         _check(lib().pmdi_export_state(self.h, int(chain), _ptr(particle), _ptr(counts), _ptr(cn), _ptr(mx)))
         return {"particle": particle, "counts": counts, "cluster_n": cn, "max_id": mx}
+
+    def chain_costs(self):
+        out = np.zeros(self.C, dtype=np.int64)
+        _check(lib().pmdi_chain_costs(self.h, _ptr(out)))
+        return out
 
     def phase_timers(self, chain=0):
         out = np.zeros(16, dtype=np.int64)

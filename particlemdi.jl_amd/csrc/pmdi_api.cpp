@@ -107,7 +107,8 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_cost, d_lorder;
+    bool have_order = false;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
     bool swept = false;
@@ -153,6 +154,8 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.terms_cap = h->terms_cap;
     a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
+    a.cost = (long long *)h->d_cost.p;
+    a.chain_order = (h->have_order && h->cfg.n_chains > 1) ? (const int *)h->d_lorder.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
     for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
@@ -172,7 +175,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_cost, &h->d_lorder,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -325,7 +328,8 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if ((rc = h->d_usc.ensure((size_t)C * P * 8)) || (rc = h->d_partstar.ensure((size_t)C * P * 4)) ||
         (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
-        (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))))
+        (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
+        (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)))
         return bail(rc);
 
     // null-cluster marginal (src/pmdi.jl:120-128): all rows in one cluster, all features on
@@ -366,6 +370,14 @@ int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16)
     return PMDI_OK;
 }
 
+int pmdi_chain_costs(pmdi_handle *h, int64_t *out)
+{
+    if (!h || !out) return fail(PMDI_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_cost.p, (size_t)h->cfg.n_chains * 8, hipMemcpyDeviceToHost));
+    return PMDI_OK;
+}
 int pmdi_block_threads(const pmdi_handle *h) { return h ? h->T : 0; }
 int64_t pmdi_lds_bytes(const pmdi_handle *h)
 {
@@ -398,6 +410,11 @@ int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const i
     hipStream_t st = (hipStream_t)stream;   // used verbatim: NULL is the device's default (null) stream
     hipError_t e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, h->cfg.n_chains, h->T, st);
     if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
+    if (h->cfg.n_chains > 1) {
+        e = pmdi_launch_chain_order((const long long *)h->d_cost.p, (int *)h->d_lorder.p, h->cfg.n_chains, st);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "chain-order launch: %s", hipGetErrorString(e));
+        h->have_order = true;
+    }
     h->swept = true; h->last_n1 = n1;
     return PMDI_OK;
 }
@@ -449,6 +466,11 @@ int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t 
     a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
     hipError_t e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, h->stream);
     if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
+    if (C > 1) {
+        e = pmdi_launch_chain_order((const long long *)h->d_cost.p, (int *)h->d_lorder.p, C, h->stream);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "chain-order launch: %s", hipGetErrorString(e));
+        h->have_order = true;
+    }
     std::vector<int> so(s32.size()), ps(C), er(C);
     std::vector<long long> stv((size_t)C * 8);
     HIP_TRY(hipMemcpyAsync(so.data(), h->d_s_out.p, so.size() * 4, hipMemcpyDeviceToHost, h->stream));

@@ -86,6 +86,8 @@ struct SweepArgs {
     int *partstar;              // [chain][P]
     int *kstate;                // [chain][KMAX][2]  final (max id, particle buffer) per dataset
     long long *phase;           // [chain][16] per-phase shader-clock totals of lane 0, or null
+    long long *cost;            // [chain] shader cycles this chain's sweep took (drives the next launch order)
+    const int *chain_order;     // [n_chains] workgroup b sweeps chain chain_order[b] (heaviest first), or null
 };
 
 struct ClusterBatchArgs {
@@ -115,4 +117,5 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
 hipError_t pmdi_launch_cluster_add(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logprob(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_t stream);
+hipError_t pmdi_launch_chain_order(const long long *cost, int *order, int n_chains, hipStream_t stream);
 hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream);

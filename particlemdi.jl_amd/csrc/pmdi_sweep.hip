@@ -219,7 +219,7 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                      \
     const SweepArgs &a = *ap;                                                                  \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                             \
-    const int chain = blockIdx.x;                                                              \
+    const int chain = a.chain_order ? a.chain_order[blockIdx.x] : (int)blockIdx.x;            \
     const int K = a.K, N = a.N, P = a.P, cap = a.cap;                                          \
     const long long n = a.n, n1 = a.n1;                                                        \
     const unsigned long long seed = a.seed + (unsigned long long)chain;                        \
@@ -901,6 +901,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 {
     PMDI_PREAMBLE;
 
+    const long long t_start = clock64();
     long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
     long long st_fast = 0, st_conv = 0, st_slow = 0;
     long long ph_last = 0;
@@ -1399,19 +1400,42 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     }
 
     if (failed) {
-        if (tid == 0) a.err[chain] = -4;  // PMDI_E_POOL
+        if (tid == 0) { a.err[chain] = -4; a.cost[chain] = clock64() - t_start; }  // PMDI_E_POOL
         return;
     }
 
     PH(11);
     sweep_final<T>(ap, st_nops, st_nres, st_nclones, st_maxid, st_sumcls, st_fast, st_conv, st_slow);
     PH(12);
+    if (tid == 0) a.cost[chain] = clock64() - t_start;
     if (a.phase && tid == 0) { sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0; }
     __syncthreads();
     if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
 }
 
+// Launch order for the next sweep: chains sorted by the cycles their last sweep took, heaviest
+// first (longest-processing-time order: the few slow chains start at once and the many fast ones
+// fill in behind them, instead of a slow chain starting last and leaving the GPU idle).
+__global__ void chain_order_kernel(const long long *cost, int *order, int n_chains)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains) return;
+    const long long mine = cost[c];
+    int rank = 0;
+    for (int j = 0; j < n_chains; ++j) {
+        const long long o = cost[j];
+        rank += (o > mine || (o == mine && j < c)) ? 1 : 0;
+    }
+    order[rank] = c;
+}
+
 }  // namespace
+
+hipError_t pmdi_launch_chain_order(const long long *cost, int *order, int n_chains, hipStream_t stream)
+{
+    hipLaunchKernelGGL(chain_order_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, cost, order, n_chains);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------
 size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T)
