@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--chains", type=int, default=4096, help="independent chains per GPU (one workgroup each)")
+    ap.add_argument("--chains", type=int, default=2048, help="independent chains per GPU (one workgroup each)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n of the workload (debug only)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")

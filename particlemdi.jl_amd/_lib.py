@@ -11,7 +11,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libpmdi_hip.so")
+LIB_PATH = os.environ.get("PMDI_LIB_PATH") or os.path.join(_PKG, "libpmdi_hip.so")   # override: A/B builds only
 _SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_api.cpp")]
 _HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_PKG, "csrc", "pmdi_device.h"),
             os.path.join(_ROOT, "include", "pmdi_hip.h")]
@@ -40,7 +40,7 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-           "-shared", "-o", LIB_PATH] + _SOURCES
+           "-shared", "-o", LIB_PATH] + os.environ.get("PMDI_EXTRA_HIPCC_FLAGS", "").split() + _SOURCES
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

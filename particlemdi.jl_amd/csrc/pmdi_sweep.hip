@@ -86,6 +86,20 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Inlining policy of the cold paths (A/B-tested: see DESIGN.md section 6)
+#ifndef PMDI_COLD_PREFIX
+#define PMDI_COLD_PREFIX __noinline__
+#endif
+#ifndef PMDI_COLD_SLOW
+#define PMDI_COLD_SLOW __forceinline__   // out-of-line cost 12% on converged chains (call-site spills in the step loop)
+#endif
+#ifndef PMDI_COLD_RESAMPLE
+#define PMDI_COLD_RESAMPLE __noinline__
+#endif
+#ifndef PMDI_COLD_FINAL
+#define PMDI_COLD_FINAL __noinline__
+#endif
+
 // ---------------------------------------------------------------------------
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
@@ -271,7 +285,7 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
 
 // reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207)
 template <int T>
-__device__ __noinline__ void sweep_prefix(const SweepArgs *__restrict__ ap)
+__device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
 {
     PMDI_PREAMBLE;
     if (tid == 0) {
@@ -409,7 +423,7 @@ __device__ __noinline__ void sweep_prefix(const SweepArgs *__restrict__ ap)
 // per-id tables in global memory.  `converted`: the fast path already drew the allocations but
 // its LDS census overflowed.  Results (clones, classes, pool overflow) go back through sh.misc.
 template <int T>
-__device__ __noinline__ void sweep_slow(const SweepArgs *__restrict__ ap, int k, int i, long long pos, bool small,
+__device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int k, int i, long long pos, bool small,
                                         bool converted, int maxid, int ncls)
 {
     PMDI_PREAMBLE;
@@ -613,7 +627,7 @@ __device__ __noinline__ void sweep_slow(const SweepArgs *__restrict__ ap, int k,
 
 // draw_partstar (src/misc.jl:27-47), gather and compact renumbering (src/pmdi.jl:318-340)
 template <int T>
-__device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, long long pos, double mx)
+__device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ ap, long long pos, double mx)
 {
     PMDI_PREAMBLE;
             // draw_partstar (src/misc.jl:27-47)
@@ -836,7 +850,7 @@ __device__ __noinline__ void sweep_resample(const SweepArgs *__restrict__ ap, lo
 
 // particle pick (src/pmdi.jl:345-350), s = sstar[p_star,:,:] (:373), counters
 template <int T>
-__device__ __noinline__ void sweep_final(const SweepArgs *__restrict__ ap, long long st_nops, long long st_nres,
+__device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap, long long st_nops, long long st_nres,
                                          long long st_nclones, long long st_maxid, long long st_sumcls,
                                          long long st_fast, long long st_conv, long long st_slow)
 {
