@@ -38,7 +38,7 @@
 /* ------------------------------------------------------------------------ */
 /* RNG: Philox4x32-10 (Salmon et al., SC'11).  Specification shared with the
  * HIP path: key = (seed lo, seed hi); ctr = (p, pos, site<<16 | k, iter);
- * u = ((w0>>5)*2^26 + (w1>>6)) * 2^-53 in [0,1). */
+ * u = (2*((w0>>6)*2^26 + (w1>>6)) + 1) * 2^-53 in (0,1). */
 enum { SITE_DRAW = 0, SITE_RESAMPLE_U = 1, SITE_RESAMPLE_SLOT = 2, SITE_PSTAR = 3, SITE_FEATSEL = 4 };
 
 void pmdi_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
@@ -65,8 +65,11 @@ double pmdi_oracle_uniform(uint64_t seed, uint32_t iter, uint32_t pos, uint32_t 
     uint32_t key[2] = { (uint32_t)seed, (uint32_t)(seed >> 32) };
     uint32_t w[4];
     pmdi_oracle_philox4x32_10(ctr, key, w);
-    uint64_t m = ((uint64_t)(w[0] >> 5) << 26) | (uint64_t)(w[1] >> 6);
-    return (double)m * (1.0 / 9007199254740992.0);
+    /* 52 random bits -> an odd multiple of 2^-53: uniform on the OPEN interval (0,1), exactly
+     * representable, never 0 (rand() at src/pmdi.jl:253 is in [0,1); excluding the single point 0
+     * lets a numerically one-hot CDF decide a draw without looking at u) */
+    uint64_t m = ((uint64_t)(w[0] >> 6) << 26) | (uint64_t)(w[1] >> 6);
+    return (double)(2 * m + 1) * (1.0 / 9007199254740992.0);
 }
 
 /* ------------------------------------------------------------------------ */

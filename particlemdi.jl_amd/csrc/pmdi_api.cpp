@@ -78,7 +78,7 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
         d.o_sstar = take((size_t)n_rows_sstar * P);
         d.o_clslead = take((size_t)P * 4);
         d.o_clsval = take((size_t)P * 4);
-        d.o_cdf = take((size_t)P * (N + 1) * 8);
+        d.o_cdf = take((size_t)P * (N + 2) * 8);
         d.o_dl = take((size_t)3 * P * 4);
     }
     d.o_cn = take(ids * 4);

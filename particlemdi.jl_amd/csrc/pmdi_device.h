@@ -22,8 +22,9 @@ __device__ __forceinline__ double uniform01(unsigned long long seed, unsigned it
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    unsigned long long m = ((unsigned long long)(c0 >> 5) << 26) | (unsigned long long)(c1 >> 6);
-    return (double)m * (1.0 / 9007199254740992.0);
+    // 52 random bits -> odd multiple of 2^-53: uniform on the open interval (0,1), never 0
+    unsigned long long m = ((unsigned long long)(c0 >> 6) << 26) | (unsigned long long)(c1 >> 6);
+    return (double)(2 * m + 1) * (1.0 / 9007199254740992.0);
 }
 
 // ---------------------------------------------------------------------------

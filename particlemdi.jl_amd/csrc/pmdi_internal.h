@@ -54,7 +54,7 @@ struct DsetDev {
     size_t o_sstar;         // uchar [n][P]  allocation history (0-based labels)
     size_t o_clslead;       // int  [P]   class slot -> leader particle
     size_t o_clsval;        // int  [P]   class slot -> class value
-    size_t o_cdf;           // double [P][N+1]  per class slot: CDF, then log-increment
+    size_t o_cdf;           // double [P][N+2]  per class slot: CDF, log-increment, one-hot label or -1
     size_t o_dl;            // int  [3][P]  distinct chosen ids this step: src, dst, new n
 };
 

@@ -129,7 +129,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.leaf_carry = take(64 * 8);
     c.leaf_prog = take(256);
     c.lpl = take((size_t)PMDI_ITEM_CAP * 8);
-    c.cdf = take((size_t)(PMDI_ITEM_CAP + PMDI_ITEM_CAP / 2 + 2) * 8);
+    c.cdf = take((size_t)(2 * PMDI_ITEM_CAP + 4) * 8);      // rows of N + 2: CDF, log-increment, one-hot label
     c.need = take((size_t)PMDI_ITEM_CAP * 4);
     c.need_slot = take((size_t)PMDI_ITEM_CAP * 4);
     c.item_id = take((size_t)PMDI_ITEM_CAP * 4);
@@ -473,7 +473,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         bool fresh = false;
                         if (valid) {
                             const int cls = pidk[p];
-                            const double *row = cdfp + (size_t)sh.slot_of[cls] * (N + 1);
+                            const double *row = cdfp + (size_t)sh.slot_of[cls] * (N + 2);
                             if (p != 0) {
                                 const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
                                 for (int t = 0; t < N - 1; ++t) {
@@ -1132,9 +1132,22 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const double fN = wv[gbase + N - 1];
+                    const double cd = c / fN;
+                    // one-hot to working precision?  every uniform is an odd multiple of 2^-53, so a
+                    // label whose CDF is < 2^-53 is never chosen and one whose CDF is 1.0 always
+                    // stops the search: the draw (:252-260) is then the same label for every u
+                    const unsigned long long m_one = __ballot(valid && (cd == 1.0 || nn == N - 1));
+                    const unsigned long long m_tiny = __ballot(valid && cd < 0x1p-53);
                     if (valid) {
-                        cdfp[(size_t)r * (N + 1) + nn] = c / fN;
-                        if (nn == N - 1) cdfp[(size_t)r * (N + 1) + N] = log(fN) + m;
+                        cdfp[(size_t)r * (N + 2) + nn] = cd;
+                        if (nn == N - 1) {
+                            cdfp[(size_t)r * (N + 2) + N] = log(fN) + m;
+                            const unsigned long long grp = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << gbase);
+                            const int nstar = __ffsll((long long)((m_one & grp) >> gbase)) - 1;
+                            const unsigned long long below = (nstar == 0) ? 0ull : ((1ull << nstar) - 1ull);
+                            const bool onehot = (((m_tiny & grp) >> gbase) & below) == below;
+                            cdfp[(size_t)r * (N + 2) + N + 1] = onehot ? (double)nstar : -1.0;
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -1170,8 +1183,11 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     int ns = 0, c = 0, kidx = 0;
                     if (valid) {
                         const int r = sh.slot_of[pidk[p]];
-                        const double *row = gen(sh.cdf + (size_t)r * (N + 1));
-                        if (p != 0) {
+                        const double *row = gen(sh.cdf + (size_t)r * (N + 2));
+                        const int hot = (int)row[N + 1];
+                        if (p != 0 && hot >= 0) {
+                            ns = hot;                                // one-hot CDF: no random number needed
+                        } else if (p != 0) {
                             const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
                             // first label whose CDF exceeds u (:252-260); the CDF is non-decreasing, so
                             // that is the number of leading entries that do not exceed u
