@@ -101,13 +101,20 @@ struct pmdi_handle {
     long long cap = 0;
     int Dmax = 0, sumD = 0, npairs = 1;
     int terms_cap = 0, pid_lds = 0, pp_lds = 0, two_per_cu = 0;
+    // light group (block_threads == 0 only): chains whose last sweep met few live clusters per step are
+    // swept by 256-thread workgroups on a second stream, concurrently with the wide workgroups of the rest
+    bool split = false;
+    int l_terms_cap = 0, l_pid_lds = 0, l_pp_lds = 0;
+    long long light_ids = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool phase_on = false;
     hipStream_t stream = nullptr;
     DsetDev ds[PMDI_KMAX_I]{};
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_cost, d_lorder;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_group, d_cost, d_lorder;
     bool have_order = false;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
@@ -155,10 +162,45 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.cost = (long long *)h->d_cost.p;
-    a.chain_order = (h->have_order && h->cfg.n_chains > 1) ? (const int *)h->d_lorder.p : nullptr;
+    a.chain_order = h->have_order ? (const int *)h->d_lorder.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
     for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
+}
+
+// One sweep of all chains on stream `st`: a single launch, or (automatic width) the heavy chains in
+// wide workgroups on `st` and the light ones in 256-thread workgroups on the handle's second stream,
+// forked from and joined back into `st`.  Then the launch order and groups of the next sweep.
+int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
+{
+    const int C = h->cfg.n_chains;
+    hipError_t e;
+    if (!h->split) {
+        e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, st);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
+    } else {
+        HIP_TRY(hipEventRecord(h->ev_fork, st));
+        a.group_flag = (const unsigned char *)h->d_group.p;
+        a.group_sel = 1;
+        e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, st);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (heavy group): %s", hipGetErrorString(e));
+        SweepArgs al = a;
+        al.group_sel = 0;
+        al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds;
+        HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+        e = pmdi_launch_sweep(al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (light group): %s", hipGetErrorString(e));
+        HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
+        HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+    }
+    if (C > 1 || h->split) {
+        const long long steps = (a.n - a.n1 + 1) * (long long)a.K;
+        e = pmdi_launch_chain_order((const long long *)h->d_cost.p, (int *)h->d_lorder.p, a.stats,
+                                    h->split ? (unsigned char *)h->d_group.p : nullptr, h->light_ids * steps, C, st);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "chain-order launch: %s", hipGetErrorString(e));
+        h->have_order = true;
+    }
+    return PMDI_OK;
 }
 
 }  // namespace
@@ -175,10 +217,13 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_cost, &h->d_lorder,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_group, &h->d_cost, &h->d_lorder,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
     return PMDI_OK;
 }
@@ -300,37 +345,51 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     h->T = cfg->block_threads ? cfg->block_threads : (P >= 2048 ? 1024 : (P > 256 ? 512 : 256));
     if (h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 256, 512 or 1024"));
     {
-        // LDS term buffer: at least P doubles (resampling weights) and a few rows of 2*D+1
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
-        int tc = env_int("PMDI_TERMS_CAP", 1024);
-        if (tc < P) tc = P;                                   // resampling weights
-        if (tc < (h->T / 64) * 128) tc = (h->T / 64) * 128;   // per-wave CDF exchange areas
-        if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
-        h->terms_cap = tc;
         if (2 * N > PMDI_ITEM_CAP) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));
         h->two_per_cu = env_int("PMDI_TWO_PER_CU", 1);
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
-        SweepArgs a;
-        h->pid_lds = 1; h->pp_lds = 1;
-        fill_sweep_common(h, a);
-        if (pmdi_sweep_lds_bytes(a, h->T) > 150 * 1024) {      // class ids of K*P particles do not fit: keep them in global memory
-            h->pid_lds = 0;
+        // per workgroup width: LDS term buffer (at least P doubles for the resampling weights, the
+        // per-wave CDF exchange areas, a few rows of 2*D+1) and which per-particle tables fit LDS
+        auto configure = [&](int T, int &terms_cap, int &pid_lds, int &pp_lds) -> int {
+            int tc = env_int("PMDI_TERMS_CAP", 1024);
+            if (tc < P) tc = P;
+            if (tc < (T / 64) * 128) tc = (T / 64) * 128;
+            if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
+            terms_cap = tc;
+            SweepArgs a;
             fill_sweep_common(h, a);
+            a.terms_cap = tc; a.pid_lds = 1; a.pp_lds = 1;
+            if (pmdi_sweep_lds_bytes(a, T) > 150 * 1024) a.pid_lds = 0;   // class ids of K*P particles do not fit: global memory
+            if (pmdi_sweep_lds_bytes(a, T) > 150 * 1024) a.pp_lds = 0;    // nor does the per-particle step scratch
+            pid_lds = a.pid_lds; pp_lds = a.pp_lds;
+            if (pmdi_sweep_lds_bytes(a, T) > 160 * 1024)
+                return fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, T));
+            return 0;
+        };
+        if ((rc = configure(h->T, h->terms_cap, h->pid_lds, h->pp_lds))) return bail(rc);
+        // automatic width: split the chains of a sweep into a heavy and a light launch
+        h->split = cfg->block_threads == 0 && h->T > 256 && env_int("PMDI_SPLIT", 1) != 0;
+        h->light_ids = env_int("PMDI_LIGHT_IDS", 40);
+        if (h->split) {
+            if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds)) h->split = false;
         }
-        if (pmdi_sweep_lds_bytes(a, h->T) > 150 * 1024) {      // nor does the per-particle step scratch
-            h->pp_lds = 0;
-            fill_sweep_common(h, a);
+        if (h->split) {
+            if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+                return bail(fail(PMDI_E_DEVICE, "stream/event creation failed"));
         }
-        if (pmdi_sweep_lds_bytes(a, h->T) > 160 * 1024)
-            return bail(fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, h->T)));
     }
     const int C = cfg->n_chains;
     if ((rc = h->d_usc.ensure((size_t)C * P * 8)) || (rc = h->d_partstar.ensure((size_t)C * P * 4)) ||
         (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
         (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
-        (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)))
+        (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
+        (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
         return bail(rc);
+    if (hipMemset(h->d_group.p, 1, (size_t)C) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));   // first sweep: every chain is heavy
 
     // null-cluster marginal (src/pmdi.jl:120-128): all rows in one cluster, all features on
     {
@@ -408,13 +467,8 @@ int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const i
     a.trace = nullptr; a.trace_on = 0;
     a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
     hipStream_t st = (hipStream_t)stream;   // used verbatim: NULL is the device's default (null) stream
-    hipError_t e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, h->cfg.n_chains, h->T, st);
-    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
-    if (h->cfg.n_chains > 1) {
-        e = pmdi_launch_chain_order((const long long *)h->d_cost.p, (int *)h->d_lorder.p, h->cfg.n_chains, st);
-        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "chain-order launch: %s", hipGetErrorString(e));
-        h->have_order = true;
-    }
+    const int lrc = launch_sweep_groups(h, a, st);
+    if (lrc) return lrc;
     h->swept = true; h->last_n1 = n1;
     return PMDI_OK;
 }
@@ -464,13 +518,7 @@ int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t 
     a.stats = (long long *)h->d_stats.p; a.err = (int *)h->d_err.p;
     a.trace = trace ? (double *)h->d_trace.p : nullptr; a.trace_on = trace ? 1 : 0;
     a.uscratch = (double *)h->d_usc.p; a.partstar = (int *)h->d_partstar.p; a.kstate = (int *)h->d_kstate.p;
-    hipError_t e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, h->stream);
-    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
-    if (C > 1) {
-        e = pmdi_launch_chain_order((const long long *)h->d_cost.p, (int *)h->d_lorder.p, C, h->stream);
-        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "chain-order launch: %s", hipGetErrorString(e));
-        h->have_order = true;
-    }
+    if ((rc = launch_sweep_groups(h, a, h->stream))) return rc;
     std::vector<int> so(s32.size()), ps(C), er(C);
     std::vector<long long> stv((size_t)C * 8);
     HIP_TRY(hipMemcpyAsync(so.data(), h->d_s_out.p, so.size() * 4, hipMemcpyDeviceToHost, h->stream));

@@ -88,6 +88,8 @@ struct SweepArgs {
     long long *phase;           // [chain][16] per-phase shader-clock totals of lane 0, or null
     long long *cost;            // [chain] shader cycles this chain's sweep took (drives the next launch order)
     const int *chain_order;     // [n_chains] workgroup b sweeps chain chain_order[b] (heaviest first), or null
+    const unsigned char *group_flag;  // [n_chains] 1 = heavy chain (many private clusters), 0 = light; or null
+    int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
 };
 
 struct ClusterBatchArgs {
@@ -117,5 +119,6 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
 hipError_t pmdi_launch_cluster_add(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logprob(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_t stream);
-hipError_t pmdi_launch_chain_order(const long long *cost, int *order, int n_chains, hipStream_t stream);
+hipError_t pmdi_launch_chain_order(const long long *cost, int *order, const long long *stats, unsigned char *group_flag,
+                                   long long light_ops_max, int n_chains, hipStream_t stream);
 hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream);

@@ -229,12 +229,13 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
     return (int)carry;
 }
 
-#define PMDI_PREAMBLE                                                                         \
+#define PMDI_PREAMBLE PMDI_PREAMBLE_K(false)
+#define PMDI_PREAMBLE_K(K1_)                                                                  \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                      \
     const SweepArgs &a = *ap;                                                                  \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                             \
     const int chain = a.chain_order ? a.chain_order[blockIdx.x] : (int)blockIdx.x;            \
-    const int K = a.K, N = a.N, P = a.P, cap = a.cap;                                          \
+    const int K = (K1_) ? 1 : a.K, N = a.N, P = a.P, cap = a.cap;                              \
     const long long n = a.n, n1 = a.n1;                                                        \
     const unsigned long long seed = a.seed + (unsigned long long)chain;                        \
     const unsigned iter = a.iter;                                                              \
@@ -910,10 +911,14 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap, lo
 // ---------------------------------------------------------------------------
 // WPS = minimum waves per SIMD the register allocation must allow (2 co-resident chains per CU
 // at T = 512 need 4)
-template <int T, int WPS>
+// K1: single-dataset models (K == 1) get a specialisation in which the dataset index is a
+// compile-time 0, so the per-dataset views are loop invariants of the sweep loop.
+template <int T, int WPS, bool K1>
 __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__restrict__ ap)
 {
-    PMDI_PREAMBLE;
+    PMDI_PREAMBLE_K(K1);
+    // two launches share the chains of a sweep (heavy: wide workgroups, light: narrow ones)
+    if (a.group_flag && (int)a.group_flag[chain] != a.group_sel) return;
 
     const long long t_start = clock64();
     long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
@@ -1438,7 +1443,12 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     sweep_final<T>(ap, st_nops, st_nres, st_nclones, st_maxid, st_sumcls, st_fast, st_conv, st_slow);
     PH(12);
     if (tid == 0) a.cost[chain] = clock64() - t_start;
-    if (a.phase && tid == 0) { sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0; }
+    if (a.phase && tid == 0) {
+        sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0;
+        // where wave 0 ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID, for the co-residency study
+        sh.ph[12] = (long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
+        sh.ph[13] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));
+    }
     __syncthreads();
     if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
 }
@@ -1446,10 +1456,14 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 // Launch order for the next sweep: chains sorted by the cycles their last sweep took, heaviest
 // first (longest-processing-time order: the few slow chains start at once and the many fast ones
 // fill in behind them, instead of a slow chain starting last and leaving the GPU idle).
-__global__ void chain_order_kernel(const long long *cost, int *order, int n_chains)
+__global__ void chain_order_kernel(const long long *cost, int *order, const long long *stats, unsigned char *group_flag,
+                                   long long light_ops_max, int n_chains)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chains) return;
+    // group of the next sweep: a chain is light when its sweep met few live clusters per step
+    // (stats[0] = sum over steps of the live-cluster count, the reference's n_operations)
+    if (group_flag) group_flag[c] = (stats[(size_t)c * 8] > light_ops_max) ? 1 : 0;
     const long long mine = cost[c];
     int rank = 0;
     for (int j = 0; j < n_chains; ++j) {
@@ -1461,9 +1475,11 @@ __global__ void chain_order_kernel(const long long *cost, int *order, int n_chai
 
 }  // namespace
 
-hipError_t pmdi_launch_chain_order(const long long *cost, int *order, int n_chains, hipStream_t stream)
+hipError_t pmdi_launch_chain_order(const long long *cost, int *order, const long long *stats, unsigned char *group_flag,
+                                   long long light_ops_max, int n_chains, hipStream_t stream)
 {
-    hipLaunchKernelGGL(chain_order_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, cost, order, n_chains);
+    hipLaunchKernelGGL(chain_order_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, cost, order, stats, group_flag,
+                       light_ops_max, n_chains);
     return hipGetLastError();
 }
 
@@ -1481,9 +1497,12 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
     const size_t lds = pmdi_sweep_lds_bytes(a, T);
     const bool two = a.two_per_cu != 0;
     const void *fn = nullptr;
-    if (T == 1024) fn = (const void *)pmdi_sweep_kernel<1024, 4>;
-    else if (T == 512) fn = two ? (const void *)pmdi_sweep_kernel<512, 4> : (const void *)pmdi_sweep_kernel<512, 2>;
-    else if (T == 256) fn = two ? (const void *)pmdi_sweep_kernel<256, 2> : (const void *)pmdi_sweep_kernel<256, 1>;
+    const bool k1 = a.K == 1;
+    if (T == 1024) fn = k1 ? (const void *)pmdi_sweep_kernel<1024, 4, true> : (const void *)pmdi_sweep_kernel<1024, 4, false>;
+    else if (T == 512 && two) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 4, true> : (const void *)pmdi_sweep_kernel<512, 4, false>;
+    else if (T == 512) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 2, true> : (const void *)pmdi_sweep_kernel<512, 2, false>;
+    else if (T == 256 && k1) fn = (const void *)pmdi_sweep_kernel<256, 2, true>;
+    else if (T == 256) fn = two ? (const void *)pmdi_sweep_kernel<256, 2, false> : (const void *)pmdi_sweep_kernel<256, 1, false>;
     else return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -8,7 +8,8 @@ from particlemdi_jl_amd import workloads
 from particlemdi_jl_amd.batched import DeviceGibbsK1
 chains = int(sys.argv[1]); warm = int(sys.argv[2])
 w = workloads.make("cfg2")
-g = DeviceGibbsK1(w["data"][0], "gaussian", w["N"], w["P"], chains, seed=1000, pool_cap=int(os.environ.get("PMDI_POOL_CAP", "0")))
+g = DeviceGibbsK1(w["data"][0], "gaussian", w["N"], w["P"], chains, seed=1000, pool_cap=int(os.environ.get("PMDI_POOL_CAP", "0")), block_threads=int(os.environ.get("PMDI_BLOCK", "0")))
+print("block", g.sw.block_threads, "lds bytes", g.sw.lds_bytes)
 n_s = g.n - g.n1 + 1
 for it in range(warm + 2):
     g.iteration(time_kernel=True); g.finish_timing(); st = g.check()

@@ -20,7 +20,7 @@ for it in range(warm + 3):
     sel = int(np.argsort(ids)[len(ids) // 2]) if len(sys.argv) > 5 else 0
     ph = g.sw.phase_timers(sel).astype(np.float64)
     clk_total, rt_total = ph[14], ph[15]
-    ph = ph[:14]
+    ph = ph[:12]
     tot = ph.sum()
     n_s = g.n - g.n1 + 1
     print(f"it {it} chain {sel} ids {ids[sel]:.0f} fast/conv/slow {st[sel,5]}/{st[sel,6]}/{st[sel,7]}: wall {dt*1e3:8.1f} ms  ids/step {st[:,0].mean()/n_s:7.1f} cls/step {st[:,4].mean()/n_s:5.2f} resamp {st[:,1].mean():5.1f} clones {st[:,2].mean():7.1f} | "
