@@ -87,6 +87,12 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // Inlining policy of the cold paths (A/B-tested: see DESIGN.md section 6)
+// waves per SIMD the 256-thread build is register-capped for.  2 = the full 256 VGPRs (no spills).
+// Measured: 3 (168 VGPRs, 73 spill slots) makes a converged chain 18% slower (156 vs 132 ms), which
+// a third chain per CU would not win back after the LDS tables had been shrunk to fit.
+#ifndef PMDI_LIGHT_WPS
+#define PMDI_LIGHT_WPS 2
+#endif
 #ifndef PMDI_COLD_PREFIX
 #define PMDI_COLD_PREFIX __noinline__
 #endif
@@ -104,7 +110,7 @@ __device__ __forceinline__ void lds_barrier()
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
         need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v,
-        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, lab, misc, ph,
+        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, lab, misc, ph,
         fl, news, total;
 };
 
@@ -122,6 +128,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.kncls = take(PMDI_KMAX_I * 4);
     c.kcur = take(PMDI_KMAX_I * 4);
     c.knflag = take(PMDI_KMAX_I * 4);
+    c.khint = take(PMDI_KMAX_I * 4);
     c.lab = take(256 * 3 * 4);
     c.leaf_i1 = take(64 * 4);
     c.leaf_n = take(64 * 4);
@@ -178,7 +185,7 @@ struct Sh {
     lint leaf_i1, leaf_n;
     ldbl leaf_tot, leaf_carry;
     lu8 leaf_prog;
-    lint kmaxid, kncls, kcur, knflag, lab, misc;
+    lint kmaxid, kncls, kcur, knflag, khint, lab, misc;
     li64 ph;
     lu8 fl, news;
 };
@@ -253,6 +260,12 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
     (void)lane; (void)wave; (void)cap; (void)n1; (void)seed; (void)iter; (void)Dp; (void)H;    \
     (void)s_in; (void)order; (void)Pi; (void)logphi; (void)flags; (void)usc; (void)pstar_raw
 
+__device__ __forceinline__ int opaque_vgpr(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem, Sh &sh)
 {
     const int H = PMDI_HT_SIZE;
@@ -275,7 +288,7 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
         sh.bm_fresh = (lu32)(smem + c.bm_fresh); sh.bm_clone = (lu32)(smem + c.bm_clone);
         sh.leaf_i1 = (lint)(smem + c.leaf_i1); sh.leaf_n = (lint)(smem + c.leaf_n);
         sh.leaf_tot = (ldbl)(smem + c.leaf_tot); sh.leaf_carry = (ldbl)(smem + c.leaf_carry); sh.leaf_prog = (lu8)(smem + c.leaf_prog);
-        sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag);
+        sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag); sh.khint = (lint)(smem + c.khint);
         sh.lab = (lint)(smem + c.lab); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph);
         sh.fl = (lu8)(smem + c.fl); sh.news = (lu8)(smem + c.news);
 }
@@ -420,14 +433,61 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
 
 }
 
+// deepcopy + cluster_add! of every distinct chosen cluster (src/pmdi.jl:297,:300): lanes =
+// (cluster, feature).  item(j, src, dst, nnew) names the j-th chosen cluster.  The clusters of a
+// chain that still carries hundreds of private copies are spread over megabytes of pool, so
+// every statistic is an HBM miss: a lane fetches several of them before it touches the first.
+template <int T, class Item>
+__device__ __forceinline__ void stats_update_all(const DsetDev &d, const KS &s, const unsigned char *flk, const double *xs,
+                                                 int nd, int D, int tid, Item item)
+{
+    const int total = nd * D;
+    int it = tid;
+    if (d.kind == K_GAUSSIAN) {
+        constexpr int U = 4;   // 8 spills in the 128-register build and is slower
+        for (; it + (U - 1) * T < total; it += U * T) {
+            int src[U], dst[U], nnew[U], q[U];
+            double2 sb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = it + u * T, j = t / D;
+                q[u] = t - j * D;
+                item(j, src[u], dst[u], nnew[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) sb[u] = s.sb[(size_t)src[u] * D + q[u]];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool on = flk[q[u]] != 0;
+                if (on) gauss_add_sb(xs[q[u]], nnew[u], sb[u]);
+                if (on || dst[u] != src[u]) s.sb[(size_t)dst[u] * D + q[u]] = sb[u];
+            }
+        }
+    }
+    for (; it < total; it += T) {
+        const int j = it / D, q = it - j * D;
+        int src, dst, nnew;
+        item(j, src, dst, nnew);
+        stats_update_one(d, s, flk[q], xs, src, dst, nnew, D, q);
+    }
+}
+
 // One (observation, dataset) step on the fallback path: per-particle class keys, ballot scans,
 // per-id tables in global memory.  `converted`: the fast path already drew the allocations but
 // its LDS census overflowed.  Results (clones, classes, pool overflow) go back through sh.misc.
 template <int T>
 __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int k, int i, long long pos, bool small,
-                                        bool converted, int maxid, int ncls)
+                                        bool converted, int maxid, int ncls, long long &ph_last, int &ph_cur)
 {
     PMDI_PREAMBLE;
+#define PHS(i_)                                                                 \
+    do {                                                                        \
+        if (a.phase && tid == 0) {                                              \
+            const long long t_ = clock64();                                     \
+            sh.ph[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_);         \
+        }                                                                       \
+    } while (0)
+    PHS(12);
     const DsetDev &d = a.ds[k];
     const KS s = make_ks(d, chain);
     const int D = d.D;
@@ -464,8 +524,9 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                     }
         __syncthreads();
     }
+    bool gcensus = converted;
     {
-                bool gcensus = converted;
+                const bool direct = !converted && sh.khint[k] != 0;   // skip the LDS census attempt
                 if (!converted) {
                     for (int pb = 0; pb < P; pb += T) {
                         const int p = pb + tid;
@@ -497,15 +558,19 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         int cnt;
                         if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
                         if (wave_group(c, valid, cnt)) {
-                            bool won;
-                            const int slot = ht_insert(sh.h2, c, won, 48);
-                            if (slot < 0) sh.misc[M_OVF] = 1;
-                            else { atomicAdd(gen(&sh.h2.a[slot]), cnt); atomicMin(gen(&sh.h2.b[slot]), p); }
+                            if (direct) {
+                                atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p);
+                            } else {
+                                bool won;
+                                const int slot = ht_insert(sh.h2, c, won, 48);
+                                if (slot < 0) sh.misc[M_OVF] = 1;
+                                else { atomicAdd(gen(&sh.h2.a[slot]), cnt); atomicMin(gen(&sh.h2.b[slot]), p); }
+                            }
                         }
                     }
                     __syncthreads();
-                    gcensus = sh.misc[M_OVF] != 0;
-                    if (gcensus) {   // too many distinct clusters for the LDS table: per-id tables in global memory
+                    gcensus = direct || sh.misc[M_OVF] != 0;
+                    if (gcensus && !direct) {   // too many distinct clusters for the LDS table: per-id tables in global memory
                         for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
                         for (int pb = 0; pb < P; pb += T) {
                             const int p = pb + tid;
@@ -518,6 +583,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                     }
                 }
 
+                PHS(6);
                 // -- D: ranks in particle order: fresh class keys (:266-269) and distinct chosen
                 // clusters, clone-or-in-place (:276-299)
                 unsigned long long carry = 0;
@@ -563,6 +629,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                 __syncthreads();
                 if (failed) { if (tid == 0) sh.misc[M_FAIL] = 1; __syncthreads(); return; }
 
+                PHS(7);
                 // -- E: apply: new class ids, remap cloned labels (:301-308)
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
@@ -587,6 +654,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                 // -- F: class list for the next step; scratch clean-up; sufficient-statistic update
                 // of every distinct chosen cluster (deepcopy + cluster_add!, :297,:300):
                 // lanes = (cluster, feature)
+                PHS(8);
                 {
                     unsigned long long ccarry = 0;
                     for (int pb = 0; pb < P; pb += T) {
@@ -610,20 +678,22 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                     } else {
                         for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
                     }
-                    for (int it = tid; it < nd * D; it += T) {
-                        const int j = it / D, q = it - j * D;
-                        int src, dst, nnew;
+                    PHS(13);
+                    stats_update_all<T>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
                         if (j < PMDI_DL_LDS) { src = sh.dl[j]; dst = sh.dl[PMDI_DL_LDS + j]; nnew = sh.dl[2 * PMDI_DL_LDS + j]; }
                         else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
-                        stats_update_one(d, s, flk[q], gen(sh.xs), src, dst, nnew, D, q);
-                    }
+                    });
                     new_ncls = (int)ccarry;
                     __syncthreads();
                     for (int r = tid; r < new_ncls; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
                 }
     }
-    if (tid == 0) { sh.misc[M_NCLONE] = nclone; sh.misc[M_NCLS] = new_ncls; }
+    if (tid == 0) {
+        sh.misc[M_NCLONE] = nclone; sh.misc[M_NCLS] = new_ncls;
+        sh.khint[k] = (gcensus && nd > PMDI_HT_SIZE / 4) ? 1 : 0;   // stay on the global census while it is needed
+    }
     __syncthreads();
+#undef PHS
 }
 
 // draw_partstar (src/misc.jl:27-47), gather and compact renumbering (src/pmdi.jl:318-340)
@@ -933,6 +1003,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         }                                                                       \
     } while (0)
     if (tid < 16) { sh.ph[tid] = 0; sh.misc[tid] = 0; }
+    if (tid < PMDI_KMAX_I) sh.khint[tid] = 0;
     long long ph_t0 = 0, ph_r0 = 0;
     if (a.phase && tid == 0) { ph_last = clock64(); ph_t0 = ph_last; ph_r0 = wall_clock64(); }
 
@@ -960,6 +1031,12 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         const int i = i_next;
         if (pos + 1 < n) i_next = order[pos + 1];
         for (int k = 0; k < K && !failed; ++k) {
+            // a fresh copy of the lane's index per step: addresses derived from it are recomputed
+            // each step instead of being hoisted out of the sweep loop and held (spilled) across it
+            const int tid_outer_ = tid, lane_outer_ = lane;
+            {
+            int tid = opaque_vgpr(tid_outer_), lane = opaque_vgpr(lane_outer_);
+#define FRESH_LANE_IDS() asm volatile("" : "+v"(tid), "+v"(lane))
             const DsetDev &d = a.ds[k];
             const KS s = make_ks(d, chain);
             const int D = d.D;
@@ -1017,7 +1094,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 if (CH < 1) CH = 1;
                 for (int j0 = 0; j0 < nneed; j0 += CH) {
                     const int nid = min(CH, nneed - j0);
-                    PH(2);
+                    PH(2); FRESH_LANE_IDS();
                     for (int it = tid; it < nid * D1; it += T) {
                         const int il = it / D1, q = it - il * D1;
                         const int id = small ? sh.need[j0 + il] : 1 + j0 + il;
@@ -1043,7 +1120,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         sh.term[il * RS + 2 * q + 1] = tb;
                     }
                     if (small) lds_barrier(); else __syncthreads();
-                    PH(3);
+                    PH(3); FRESH_LANE_IDS();
                     for (int il = tid; il < nid; il += T) {
                         const double *t = gen(sh.term + il * RS);
                         double out;
@@ -1083,7 +1160,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // -- B: mutation CDF per particle class (:231-248): lanes = (class, label) inside a
             // wave; max / cumsum / normalise by shuffles.  The cumsum follows Julia's
             // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
-            PH(4);
+            PH(4); FRESH_LANE_IDS();
             double *cdfp = small ? gen(sh.cdf) : s.cdf;
             {
                 const int G = 64 / N;
@@ -1163,7 +1240,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // chosen clusters (:275-310).  Fast path (the step's tables fit LDS): classes come from a
             // (class, label) key table, ranks "in particle order" from LDS bitmaps + popcounts, no
             // block-wide scans.  Fallback (burn-in): per-particle keys, ballot scans, global tables.
-            PH(5);
+            PH(5); FRESH_LANE_IDS();
             {   // prefetch the next step's observation row (dataset k+1 of this observation, or
                 // dataset 0 of the next one) into registers; it is consumed a whole step later
                 int kn = k + 1, in_ = i;
@@ -1178,7 +1255,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 for (int j = tid; j < nneed; j += T) { const int sl = sh.need_slot[j]; sh.h1.key[sl] = 0; sh.h1.a[sl] = 0; }
                 if (tid == 0) sh.misc[M_NEED] = 0;
             }
-            bool fast = small;
+            bool fast = small && sh.khint[k] == 0;   // hint: the last steps chose too many distinct clusters for the LDS census
             bool converted = false;
             int nd = 0, nclone = 0, new_ncls = 0;
             if (fast) {
@@ -1249,7 +1326,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             }
             if (fast) {
                 // -- D'1: the touched (class, label) keys and the first particle of every chosen cluster
-                PH(6);
+                PH(6); FRESH_LANE_IDS();
                 for (int w = tid; w < items; w += T) {
                     const int mp = sh.ktab_minp[w];
                     if (mp != PMDI_INF_I) {
@@ -1278,7 +1355,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 }
                 lds_barrier();
                 // -- D'2: ranks in particle order by popcounts below the particle's bit
-                PH(7);
+                PH(7); FRESH_LANE_IDS();
                 const int nk = sh.misc[M_NK], nf = sh.misc[M_NF];
                 if (wave == 0) {
                     for (int j0 = 0; j0 < nk; j0 += 64) {
@@ -1345,7 +1422,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 new_ncls = sh.misc[M_NCLS];
                 if (maxid + nclone > cap) { failed = 1; break; }
                 // -- E': apply (:301-308), sufficient statistics (:297,:300), table clean-up
-                PH(8);
+                PH(8); FRESH_LANE_IDS();
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
                     if (p < P) {
@@ -1355,17 +1432,16 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         pidk[p] = sh.ktab_val[sidp[p]];
                     }
                 }
-                for (int it = tid; it < nd * D; it += T) {
-                    const int j = it / D, q = it - j * D;
-                    stats_update_one(d, s, flk[q], gen(sh.xs), sh.fl_p[j], sh.fl_tgt[j], sh.fl_nnew[j], D, q);
-                }
+                stats_update_all<T>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
+                    src = sh.fl_p[j]; dst = sh.fl_tgt[j]; nnew = sh.fl_nnew[j];
+                });
                 for (int j = tid; j < nk; j += T) sh.ktab_minp[sh.klist[j]] = PMDI_INF_I;
                 for (int w = tid; w < 2 * ((P >> 6) + 1); w += T) { sh.bm_fresh[w] = 0; sh.bm_clone[w] = 0; }
                 lds_barrier();
                 for (int j = tid; j < nf; j += T) { const int sl = sh.fl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
                 if (tid == 0) { sh.misc[M_NK] = 0; sh.misc[M_NF] = 0; }
             } else {
-                sweep_slow<T>(ap, k, i, pos, small, converted, maxid, ncls);
+                sweep_slow<T>(ap, k, i, pos, small, converted, maxid, ncls, ph_last, ph_cur);
                 if (sh.misc[M_FAIL]) { failed = 1; break; }
                 nclone = sh.misc[M_NCLONE];
                 new_ncls = sh.misc[M_NCLS];
@@ -1377,6 +1453,8 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             if (maxid + nclone > st_maxid) st_maxid = maxid + nclone;
             if (tid == 0) { sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = new_ncls; }
             __syncthreads();
+#undef FRESH_LANE_IDS
+            }
         }
         if (failed) break;
 
@@ -1445,9 +1523,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     if (tid == 0) a.cost[chain] = clock64() - t_start;
     if (a.phase && tid == 0) {
         sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0;
-        // where wave 0 ran: HW_ID (wave/simd/cu/sh/se) and XCC_ID, for the co-residency study
-        sh.ph[12] = (long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
-        sh.ph[13] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));
     }
     __syncthreads();
     if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
@@ -1501,8 +1576,7 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
     if (T == 1024) fn = k1 ? (const void *)pmdi_sweep_kernel<1024, 4, true> : (const void *)pmdi_sweep_kernel<1024, 4, false>;
     else if (T == 512 && two) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 4, true> : (const void *)pmdi_sweep_kernel<512, 4, false>;
     else if (T == 512) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 2, true> : (const void *)pmdi_sweep_kernel<512, 2, false>;
-    else if (T == 256 && k1) fn = (const void *)pmdi_sweep_kernel<256, 2, true>;
-    else if (T == 256) fn = two ? (const void *)pmdi_sweep_kernel<256, 2, false> : (const void *)pmdi_sweep_kernel<256, 1, false>;
+    else if (T == 256) fn = k1 ? (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, true> : (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, false>;
     else return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -18,3 +18,5 @@ ids = st[:, 0] / n_s
 conv = ids < 10
 print(f"two_per_cu={os.environ.get('PMDI_TWO_PER_CU','1')} chains={chains}: kernel {g.kernel_ms[-1]:.0f} ms | converged chains ({conv.sum()}): per-chain ms p10/p50/p90 "
       f"{np.percentile(t[conv],10):.0f}/{np.percentile(t[conv],50):.0f}/{np.percentile(t[conv],90):.0f} | all: mean {t.mean():.0f} max {t.max():.0f} | sum/512 slots {t.sum()/512:.0f} ms sum/256 {t.sum()/256:.0f} ms; p99 {np.percentile(t,99):.0f} heavy(>2x median) {np.mean(t > 2*np.median(t)):.1%} of chains = {t[t > 2*np.median(t)].sum()/t.sum():.0%} of work", flush=True)
+heavy = ids > int(os.environ.get("PMDI_LIGHT_IDS", "40"))
+print(f"groups (by this sweep's ids/step): heavy {heavy.sum()} chains, sum {t[heavy].sum()/1e3:.1f} s, mean {t[heavy].mean() if heavy.any() else 0:.0f} ms, max {t[heavy].max() if heavy.any() else 0:.0f}; light {(~heavy).sum()} chains, sum {t[~heavy].sum()/1e3:.1f} s, mean {t[~heavy].mean():.0f} ms; slot-seconds available {g.kernel_ms[-1]*512/1e3:.1f}", flush=True)
