@@ -344,7 +344,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     h->sumD = flag_off;
     h->T = cfg->block_threads ? cfg->block_threads : (P >= 2048 ? 1024 : (P > 256 ? 512 : 256));
     if (!cfg->block_threads && h->T > 256 && getenv("PMDI_HEAVY_T")) h->T = atoi(getenv("PMDI_HEAVY_T"));   // tuning knob: width of the heavy group
-    if (h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 256, 512 or 1024"));
+    if (h->T != 128 && h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 128, 256, 512 or 1024"));
     {
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         if (2 * N > PMDI_ITEM_CAP) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));

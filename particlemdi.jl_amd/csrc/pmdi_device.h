@@ -28,40 +28,58 @@ __device__ __forceinline__ double uniform01(unsigned long long seed, unsigned it
 }
 
 // ---------------------------------------------------------------------------
+// Arena pointers carry the global address space: the compiler then emits global_load/global_store
+// (vmcnt only) instead of flat instructions, which also tick the LDS counter and make every LDS
+// read behind them wait for the HBM round trip.
+#define PMDI_GLOBAL __attribute__((address_space(1)))
+typedef PMDI_GLOBAL int *gint;
+typedef const PMDI_GLOBAL int *gcint;
+typedef PMDI_GLOBAL double *gdbl;
+typedef const PMDI_GLOBAL double *gcdbl;
+typedef double dbl2v __attribute__((ext_vector_type(2)));   // plain 16-byte pair: loads and stores work in any address space
+typedef PMDI_GLOBAL dbl2v *gdbl2;
+typedef PMDI_GLOBAL long long *gi64;
+typedef PMDI_GLOBAL unsigned char *gu8;
+typedef const PMDI_GLOBAL unsigned char *gcu8;
+template <class Tp> __device__ __forceinline__ PMDI_GLOBAL Tp *glob(Tp *p) { return (PMDI_GLOBAL Tp *)p; }
+template <class Tp> __device__ __forceinline__ Tp *gen(PMDI_GLOBAL Tp *p) { return (Tp *)p; }
+__device__ __forceinline__ double2 ld2(const PMDI_GLOBAL dbl2v *p, size_t i) { const dbl2v v = p[i]; return make_double2(v.x, v.y); }
+__device__ __forceinline__ void st2(PMDI_GLOBAL dbl2v *p, size_t i, double2 v) { dbl2v w; w.x = v.x; w.y = v.y; p[i] = w; }
+
 struct KS {  // pointers of one (chain, dataset)
-    int *part[2];
-    int *pid, *sid, *kv, *newid, *counts, *ncop, *firstc, *cn, *clslead, *clsval, *dl;
-    double *lp, *cdf;
-    double2 *ml, *sb;
-    int *cnt;
-    long long *nbs;
-    unsigned char *sstar;
+    gint part[2];
+    gint pid, sid, kv, newid, counts, ncop, firstc, cn, clslead, clsval, dl;
+    gdbl lp, cdf;
+    gdbl2 ml, sb;
+    gint cnt;
+    gi64 nbs;
+    gu8 sstar;
 };
 
 __device__ __forceinline__ KS make_ks(const DsetDev &d, int chain)
 {
     KS s;
     char *b = d.arena + (size_t)chain * d.stride;
-    s.part[0] = (int *)(b + d.o_particle[0]);
-    s.part[1] = (int *)(b + d.o_particle[1]);
-    s.pid = (int *)(b + d.o_pid);
-    s.sid = (int *)(b + d.o_sid);
-    s.kv = (int *)(b + d.o_kv);
-    s.newid = (int *)(b + d.o_newid);
-    s.counts = (int *)(b + d.o_counts);
-    s.ncop = (int *)(b + d.o_ncop);
-    s.firstc = (int *)(b + d.o_firstc);
-    s.lp = (double *)(b + d.o_lp);
-    s.cn = (int *)(b + d.o_cn);
-    s.ml = (double2 *)(b + d.o_ml);
-    s.sb = (double2 *)(b + d.o_sb);
-    s.cnt = (int *)(b + d.o_cnt);
-    s.nbs = (long long *)(b + d.o_nbs);
-    s.sstar = (unsigned char *)(b + d.o_sstar);
-    s.clslead = (int *)(b + d.o_clslead);
-    s.clsval = (int *)(b + d.o_clsval);
-    s.cdf = (double *)(b + d.o_cdf);
-    s.dl = (int *)(b + d.o_dl);
+    s.part[0] = glob((int *)(b + d.o_particle[0]));
+    s.part[1] = glob((int *)(b + d.o_particle[1]));
+    s.pid = glob((int *)(b + d.o_pid));
+    s.sid = glob((int *)(b + d.o_sid));
+    s.kv = glob((int *)(b + d.o_kv));
+    s.newid = glob((int *)(b + d.o_newid));
+    s.counts = glob((int *)(b + d.o_counts));
+    s.ncop = glob((int *)(b + d.o_ncop));
+    s.firstc = glob((int *)(b + d.o_firstc));
+    s.lp = glob((double *)(b + d.o_lp));
+    s.cn = glob((int *)(b + d.o_cn));
+    s.ml = glob((dbl2v *)(b + d.o_ml));
+    s.sb = glob((dbl2v *)(b + d.o_sb));
+    s.cnt = glob((int *)(b + d.o_cnt));
+    s.nbs = glob((long long *)(b + d.o_nbs));
+    s.sstar = glob((unsigned char *)(b + d.o_sstar));
+    s.clslead = glob((int *)(b + d.o_clslead));
+    s.clsval = glob((int *)(b + d.o_clsval));
+    s.cdf = glob((double *)(b + d.o_cdf));
+    s.dl = glob((int *)(b + d.o_dl));
     return s;
 }
 
@@ -122,21 +140,53 @@ __device__ __forceinline__ unsigned long long block_flag_scan(bool f0, bool f1, 
     return base + mine;
 }
 
+// Wave-level all-reduce of a double on the DPP network (no LDS round trips): xor-1 and xor-2 inside
+// quads, half-row and row mirrors give every lane its 16-lane row total; the four row totals are
+// read with v_readlane and combined as (r0 op r1) op (r2 op r3).  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);     // row_half_mirror
+    v += dpp_f64<0x140>(v);     // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+    double t;
+    t = dpp_f64<0xB1>(v); v = (t > v) ? t : v;
+    t = dpp_f64<0x4E>(v); v = (t > v) ? t : v;
+    t = dpp_f64<0x141>(v); v = (t > v) ? t : v;
+    t = dpp_f64<0x140>(v); v = (t > v) ? t : v;
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    const double m01 = (r1 > r0) ? r1 : r0, m23 = (r3 > r2) ? r3 : r2;
+    return (m23 > m01) ? m23 : m01;
+}
+
+// Block-wide max / pair of sums.  scr: 48 doubles; the max uses [32,48), the sums [0,32), so the two
+// can follow each other with one barrier each (the caller's next use of scr is barriers away).
 template <int T>
 __device__ __forceinline__ double block_max(double v, double *scr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double t = __shfl_xor(v, off);
-        v = (t > v) ? t : v;
-    }
-    if (lane == 0) scr[wave] = v;
+    v = wave_max_f64(v);
+    if (lane == 0) scr[32 + wave] = v;
     __syncthreads();
-    double m = scr[0];
+    double m = scr[32];
 #pragma unroll
-    for (int w = 1; w < T / 64; ++w) { double t = scr[w]; m = (t > m) ? t : m; }
-    __syncthreads();
+    for (int w = 1; w < T / 64; ++w) { double t = scr[32 + w]; m = (t > m) ? t : m; }
     return m;
 }
 
@@ -144,17 +194,13 @@ template <int T>
 __device__ __forceinline__ void block_sum2(double &a, double &b, double *scr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off);
-        b += __shfl_xor(b, off);
-    }
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
     if (lane == 0) { scr[wave] = a; scr[16 + wave] = b; }
     __syncthreads();
     double sa = 0.0, sb = 0.0;
 #pragma unroll
     for (int w = 0; w < T / 64; ++w) { sa += scr[w]; sb += scr[16 + w]; }
-    __syncthreads();
     a = sa; b = sb;
 }
 
@@ -301,13 +347,13 @@ __device__ __forceinline__ void stats_update_one(const DsetDev &d, const KS &s, 
                                                  int src, int dst, int nnew, int D, int q)
 {
     if (d.kind == K_GAUSSIAN) {
-        double2 sb = s.sb[(size_t)src * D + q];
+        double2 sb = ld2(s.sb, (size_t)src * D + q);
         if (on) gauss_add_sb(xs[q], nnew, sb);
-        if (on || dst != src) s.sb[(size_t)dst * D + q] = sb;
+        if (on || dst != src) st2(s.sb, (size_t)dst * D + q, sb);
     } else if (d.kind == K_CATEGORICAL) {
         const int x = ((const int *)xs)[q];
-        const int *cs = s.cnt + ((size_t)src * D + q) * d.L;
-        int *cd = s.cnt + ((size_t)dst * D + q) * d.L;
+        const gcint cs = s.cnt + ((size_t)src * D + q) * d.L;
+        const gint cd = s.cnt + ((size_t)dst * D + q) * d.L;
         if (dst != src) for (int l = 0; l < d.L; ++l) cd[l] = cs[l];
         if (on) cd[x - 1] = cs[x - 1] + 1;
     } else {
@@ -318,7 +364,7 @@ __device__ __forceinline__ void stats_update_one(const DsetDev &d, const KS &s, 
 
 // calc_logprob(::NegBinomCluster) per-feature term: negbinom_cluster.jl:33-37;
 // loggamma of integers comes from the host-built table LG[m] = lgamma(m)
-__device__ __forceinline__ double negbin_term(const double *lg, long long n, long long x, long long S)
+__device__ __forceinline__ double negbin_term(gcdbl lg, long long n, long long x, long long S)
 {
     return lg[1 + n + 1] + lg[1 + x + S] + lg[1 + n + 1 + S] - lg[1 + n + 1 + 1 + x + S] -
            lg[1 + n] - lg[1 + S];

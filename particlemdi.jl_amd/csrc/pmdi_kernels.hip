@@ -24,13 +24,13 @@ __global__ void cluster_add_kernel(const ClusterBatchArgs a)
         const bool on = a.flags ? a.flags[q] != 0 : true;
         if (!on) continue;
         if (d.kind == K_GAUSSIAN) {
-            double2 ml = s.ml[(size_t)id * D + q], sb = s.sb[(size_t)id * D + q];
-            gauss_add(d.xf[(size_t)row * D + q], nnew, ml, sb);
-            s.ml[(size_t)id * D + q] = ml; s.sb[(size_t)id * D + q] = sb;
+            double2 ml = ld2(s.ml, (size_t)id * D + q), sb = ld2(s.sb, (size_t)id * D + q);
+            gauss_add(glob(d.xf)[(size_t)row * D + q], nnew, ml, sb);
+            st2(s.ml, (size_t)id * D + q, ml); st2(s.sb, (size_t)id * D + q, sb);
         } else if (d.kind == K_CATEGORICAL) {
-            s.cnt[((size_t)id * D + q) * d.L + (d.xi[(size_t)row * D + q] - 1)] += 1;
+            s.cnt[((size_t)id * D + q) * d.L + (glob(d.xi)[(size_t)row * D + q] - 1)] += 1;
         } else {
-            s.nbs[(size_t)id * D + q] += d.xi[(size_t)row * D + q];
+            s.nbs[(size_t)id * D + q] += glob(d.xi)[(size_t)row * D + q];
         }
     }
 }
@@ -53,30 +53,30 @@ __global__ void cluster_logprob_kernel(const ClusterBatchArgs a)
         for (int q = 0; q < D; ++q) nflag += (a.flags ? a.flags[q] != 0 : 1);
         double out;
         if (d.kind == K_GAUSSIAN) {
-            out = (double)nflag * d.gtab[cn];
+            out = (double)nflag * glob(d.gtab)[cn];
             for (int q = 0; q < D; ++q) {
                 if (a.flags && !a.flags[q]) continue;
                 double ta, tb;
-                gauss_terms(d.xf[(size_t)row * D + q], (double)cn, s.ml[(size_t)id * D + q], ta, tb);
+                gauss_terms(glob(d.xf)[(size_t)row * D + q], (double)cn, ld2(s.ml, (size_t)id * D + q), ta, tb);
                 out += ta; out -= tb;
             }
         } else if (d.kind == K_CATEGORICAL) {
             double acc = 0.0;
             for (int q = 0; q < D; ++q) {
                 if (a.flags && !a.flags[q]) continue;
-                acc += d.lhtab[d.maxcol[q] + 2 * cn];
+                acc += glob(d.lhtab)[glob(d.maxcol)[q] + 2 * cn];
             }
             out = -acc;
             for (int q = 0; q < D; ++q) {
                 if (a.flags && !a.flags[q]) continue;
-                const int c = s.cnt[((size_t)id * D + q) * d.L + (d.xi[(size_t)row * D + q] - 1)];
-                out += (cn == 0) ? d.lhtab[1] : d.lhtab[2 * c + 1];
+                const int c = s.cnt[((size_t)id * D + q) * d.L + (glob(d.xi)[(size_t)row * D + q] - 1)];
+                out += (cn == 0) ? glob(d.lhtab)[1] : glob(d.lhtab)[2 * c + 1];
             }
         } else {
             out = 0.0;
             for (int q = 0; q < D; ++q) {
                 if (a.flags && !a.flags[q]) continue;
-                out += negbin_term(d.lgtab, cn, d.xi[(size_t)row * D + q], s.nbs[(size_t)id * D + q]);
+                out += negbin_term(glob(d.lgtab), cn, glob(d.xi)[(size_t)row * D + q], s.nbs[(size_t)id * D + q]);
             }
         }
         a.out[b] = out;
@@ -90,15 +90,15 @@ __device__ __forceinline__ double logmarginal_one(const DsetDev &d, int cn, doub
 {
     if (d.kind == K_GAUSSIAN) {
         const double a_n = ((double)cn / 2.0 + 0.5);
-        return (-a_n) * log(beta) + d.lmtab[cn];
+        return (-a_n) * log(beta) + glob(d.lmtab)[cn];
     } else if (d.kind == K_CATEGORICAL) {
-        const int mc = d.maxcol[q];                       // 2*nlevels_q
+        const int mc = glob(d.maxcol)[q];                       // 2*nlevels_q
         double v = 0.0;
-        v += d.lghtab[2 * mc] - d.lghtab[2 * (mc + cn)];
-        for (int r = 0; r < mc; ++r) v += d.lghtab[2 * cnt_q[r] + 1];
+        v += glob(d.lghtab)[2 * mc] - glob(d.lghtab)[2 * (mc + cn)];
+        for (int r = 0; r < mc; ++r) v += glob(d.lghtab)[2 * cnt_q[r] + 1];
         return v;
     } else {
-        return d.lgtab[S + 1] - d.lgtab[S + (cn + 1 + 1)] + d.lgtab[1 + cn];
+        return glob(d.lgtab)[S + 1] - glob(d.lgtab)[S + (cn + 1 + 1)] + glob(d.lgtab)[1 + cn];
     }
 }
 
@@ -111,8 +111,8 @@ __global__ void cluster_logmarginal_kernel(const ClusterBatchArgs a)
     for (long long it = blockIdx.x * (long long)blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(it / D), q = (int)(it - (long long)b * D);
         const int id = b + 1;
-        const double beta = d.kind == K_GAUSSIAN ? s.sb[(size_t)id * D + q].y : 0.0;
-        const int *cq = d.kind == K_CATEGORICAL ? s.cnt + ((size_t)id * D + q) * d.L : nullptr;
+        const double beta = d.kind == K_GAUSSIAN ? ld2(s.sb, (size_t)id * D + q).y : 0.0;
+        const int *cq = d.kind == K_CATEGORICAL ? gen(s.cnt + ((size_t)id * D + q) * d.L) : nullptr;
         const long long S = d.kind == K_NEGBINOM ? s.nbs[(size_t)id * D + q] : 0;
         a.out[it] = logmarginal_one(d, s.cn[id], beta, cq, S, q);
     }
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) featsel_label_kernel(const FeatSelArgs a)
             for (long long i = first; i < n; ++i) {
                 if (traj[i] != u) continue;
                 ++c;
-                gauss_add(d.xf[(size_t)i * D + q], c, ml, sb);
+                gauss_add(glob(d.xf)[(size_t)i * D + q], c, ml, sb);
             }
             val = logmarginal_one(d, cn, sb.y, nullptr, 0, q);
         } else if (d.kind == K_CATEGORICAL) {
@@ -163,14 +163,14 @@ __global__ void __launch_bounds__(256) featsel_label_kernel(const FeatSelArgs a)
             for (int l = 0; l < d.L; ++l) mine[l] = 0;
             for (long long i = first; i < n; ++i) {
                 if (traj[i] != u) continue;
-                mine[d.xi[(size_t)i * D + q] - 1] += 1;
+                mine[glob(d.xi)[(size_t)i * D + q] - 1] += 1;
             }
             val = logmarginal_one(d, cn, 0.0, mine, 0, q);
         } else {
             long long S = 0;
             for (long long i = first; i < n; ++i) {
                 if (traj[i] != u) continue;
-                S += d.xi[(size_t)i * D + q];
+                S += glob(d.xi)[(size_t)i * D + q];
             }
             val = logmarginal_one(d, cn, 0.0, nullptr, S, q);
         }

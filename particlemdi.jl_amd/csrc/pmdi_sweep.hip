@@ -38,6 +38,7 @@ typedef __attribute__((address_space(3))) unsigned char *lu8;
 // address space and emits ds_* instructions)
 template <class Tp>
 __device__ __forceinline__ Tp *gen(__attribute__((address_space(3))) Tp *p) { return (Tp *)p; }
+using pmdi_dev::gen;   // the overload for arena (global) pointers
 
 // ---------------------------------------------------------------------------
 // Open-addressing hash table in LDS: key = cluster id (0 = empty), two payload words.
@@ -121,7 +122,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     const int Dp = (a.Dmax + 15) & ~15;
     // ---- fixed-size tables: compile-time offsets ----
     c.scan = take(16 * 8);
-    c.red = take(32 * 8);
+    c.red = take(48 * 8);
     c.misc = take(16 * 4);
     c.ph = take(16 * 8);
     c.kmaxid = take(PMDI_KMAX_I * 4);
@@ -194,8 +195,33 @@ enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCL
 
 // class list of dataset k: slot r -> leader particle / class value.  The first cls_lds slots
 // live in LDS, the rest (burn-in only) in global memory.
+// A table that lives in LDS when the configuration lets it fit and in the chain's arena otherwise.
+// Which one is a launch constant: a uniform branch picks ds_* or global_* instructions (a generic
+// pointer would make every access a flat instruction).
+template <class Tp>
+struct Dual {
+    __attribute__((address_space(3))) Tp *l;
+    PMDI_GLOBAL Tp *g;
+    bool lds;
+    struct Ref {
+        const Dual &d;
+        size_t i;
+        __device__ __forceinline__ operator Tp() const { return d.lds ? d.l[i] : d.g[i]; }
+        __device__ __forceinline__ Tp operator=(Tp v) const { if (d.lds) d.l[i] = v; else d.g[i] = v; return v; }
+        __device__ __forceinline__ Tp operator+=(Tp v) const { const Tp w = Tp(*this) + v; *this = w; return w; }
+    };
+    __device__ __forceinline__ Ref operator[](size_t i) const { return Ref{*this, i}; }
+    __device__ __forceinline__ Dual operator+(size_t off) const { return Dual{l + off, g + off, lds}; }
+};
+template <class Tp>
+__device__ __forceinline__ Dual<Tp> dual(bool lds, __attribute__((address_space(3))) Tp *l, PMDI_GLOBAL Tp *g)
+{
+    return Dual<Tp>{l, g, lds};
+}
+
 struct ClsList {
-    int *l_lead, *l_val, *g_lead, *g_val;
+    lint l_lead, l_val;
+    gint g_lead, g_val;
     int cap;
     __device__ __forceinline__ int lead(int r) const { return r < cap ? l_lead[r] : g_lead[r]; }
     __device__ __forceinline__ int val(int r) const { return r < cap ? l_val[r] : g_val[r]; }
@@ -209,7 +235,7 @@ struct ClsList {
 // whose CDF the reference caches in fprob_dict, src/pmdi.jl:225-248).  lead_of must be INF
 // for every class value on entry; it is INF again on exit.  Returns the number of classes.
 template <int T>
-__device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &cl, const Sh &sh, int P)
+__device__ __forceinline__ int rebuild_classes(const Dual<int> &pidk, const ClsList &cl, const Sh &sh, int P)
 {
     const int tid = threadIdx.x;
     for (int pb = 0; pb < P; pb += T) {
@@ -250,13 +276,13 @@ __device__ __forceinline__ int rebuild_classes(const int *pidk, const ClsList &c
     const int H = PMDI_HT_SIZE;                                                                   \
     Sh sh;                                                                                     \
     build_sh(a, smem, sh);                                                                     \
-    const int *s_in = a.s_in + (size_t)chain * K * n;                                          \
-    const int *order = a.order + (size_t)chain * n;                                            \
-    const double *Pi = a.Pi + (size_t)chain * K * N;                                           \
-    const double *logphi = a.logphi + (size_t)chain * a.npairs;                                \
-    const unsigned char *flags = a.flags ? a.flags + (size_t)chain * a.sumD : nullptr;         \
-    double *usc = a.uscratch + (size_t)chain * P;                                              \
-    int *pstar_raw = a.partstar + (size_t)chain * P;                                           \
+    const gcint s_in = glob(a.s_in) + (size_t)chain * K * n;                                   \
+    const gcint order = glob(a.order) + (size_t)chain * n;                                     \
+    const gcdbl Pi = glob(a.Pi) + (size_t)chain * K * N;                                       \
+    const gcdbl logphi = glob(a.logphi) + (size_t)chain * a.npairs;                            \
+    const gcu8 flags = a.flags ? glob(a.flags) + (size_t)chain * a.sumD : (gcu8)nullptr;       \
+    const gdbl usc = glob(a.uscratch) + (size_t)chain * P;                                     \
+    const gint pstar_raw = glob(a.partstar) + (size_t)chain * P;                               \
     (void)lane; (void)wave; (void)cap; (void)n1; (void)seed; (void)iter; (void)Dp; (void)H;    \
     (void)s_in; (void)order; (void)Pi; (void)logphi; (void)flags; (void)usc; (void)pstar_raw
 
@@ -339,7 +365,7 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         const DsetDev &d = a.ds[k];
         const KS s = make_ks(d, chain);
         const int D = d.D;
-        int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
+        const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
         unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
         for (int idx = tid; idx <= cap; idx += T) { s.counts[idx] = 0; s.ncop[idx] = 0; s.firstc[idx] = PMDI_INF_I; }
         for (int idx = tid; idx < N * P; idx += T) { s.newid[idx] = 0; s.part[0][idx] = 1; }
@@ -377,7 +403,7 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         // fresh clusters 1..nu+1 (:189,:194)
         if (d.kind == K_GAUSSIAN) {
             for (int it = tid; it < (nu + 1) * D; it += T) {
-                s.sb[D + it] = make_double2(0.0, 0.5);
+                st2(s.sb, D + it, make_double2(0.0, 0.5));
             }
         } else if (d.kind == K_CATEGORICAL) {
             for (int it = tid; it < (nu + 1) * D * d.L; it += T) s.cnt[(size_t)D * d.L + it] = 0;
@@ -398,22 +424,22 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
                     const int i = order[j];
                     if (s_in[(size_t)k * n + i] != u) continue;
                     ++c;
-                    gauss_add_sb(d.xf[(size_t)i * D + q], c, sb);
+                    gauss_add_sb(glob(d.xf)[(size_t)i * D + q], c, sb);
                 }
-                s.sb[(size_t)id * D + q] = sb;
+                st2(s.sb, (size_t)id * D + q, sb);
             } else if (d.kind == K_CATEGORICAL) {
-                int *cn_ = s.cnt + ((size_t)id * D + q) * d.L;
+                const gint cn_ = s.cnt + ((size_t)id * D + q) * d.L;
                 for (long long j = 0; j < n1 - 1; ++j) {
                     const int i = order[j];
                     if (s_in[(size_t)k * n + i] != u) continue;
-                    cn_[d.xi[(size_t)i * D + q] - 1] += 1;
+                    cn_[glob(d.xi)[(size_t)i * D + q] - 1] += 1;
                 }
             } else {
                 long long S = 0;
                 for (long long j = 0; j < n1 - 1; ++j) {
                     const int i = order[j];
                     if (s_in[(size_t)k * n + i] != u) continue;
-                    S += d.xi[(size_t)i * D + q];
+                    S += glob(d.xi)[(size_t)i * D + q];
                 }
                 s.nbs[(size_t)id * D + q] = S;
             }
@@ -425,7 +451,7 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
             int nf = 0;
             for (int q = 0; q < D; ++q) nf += flk[q];
             sh.knflag[k] = nf;
-            const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
+            const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
             cl.set(0, 0, 1);
         }
         __syncthreads();
@@ -455,12 +481,12 @@ __device__ __forceinline__ void stats_update_all(const DsetDev &d, const KS &s, 
                 item(j, src[u], dst[u], nnew[u]);
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) sb[u] = s.sb[(size_t)src[u] * D + q[u]];
+            for (int u = 0; u < U; ++u) sb[u] = ld2(s.sb, (size_t)src[u] * D + q[u]);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool on = flk[q[u]] != 0;
                 if (on) gauss_add_sb(xs[q[u]], nnew[u], sb[u]);
-                if (on || dst[u] != src[u]) s.sb[(size_t)dst[u] * D + q[u]] = sb[u];
+                if (on || dst[u] != src[u]) st2(s.sb, (size_t)dst[u] * D + q[u], sb[u]);
             }
         }
     }
@@ -491,14 +517,14 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     const DsetDev &d = a.ds[k];
     const KS s = make_ks(d, chain);
     const int D = d.D;
-    int *part = s.part[sh.kcur[k]];
-    int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
-    int *sidp = a.pp_lds ? gen(sh.sid) : s.sid;
-    int *kvp = a.pp_lds ? gen(sh.kv) : s.kv;
+    const gint part = s.part[sh.kcur[k]];
+    const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+    const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
+    const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
     const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
-    const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
+    const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
     const int items = ncls * N;
-    double *cdfp = small ? gen(sh.cdf) : s.cdf;
+    const Dual<double> cdfp = dual(small, sh.cdf, s.cdf);
     int nd = 0, nclone = 0, new_ncls = 0, failed = 0;
     (void)items;
     if (converted) {
@@ -519,8 +545,8 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                             fresh = v <= 0;
                         }
                         int cnt;
-                        if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
-                        if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
+                        if (wave_group(key, fresh, cnt)) atomicMin(gen(&s.newid[key]), p - P);
+                        if (wave_group(c, valid, cnt)) { atomicAdd(gen(&s.ncop[c]), cnt); atomicMin(gen(&s.firstc[c]), p); }
                     }
         __syncthreads();
     }
@@ -535,7 +561,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         bool fresh = false;
                         if (valid) {
                             const int cls = pidk[p];
-                            const double *row = cdfp + (size_t)sh.slot_of[cls] * (N + 2);
+                            const Dual<double> row = cdfp + (size_t)sh.slot_of[cls] * (N + 2);
                             if (p != 0) {
                                 const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
                                 for (int t = 0; t < N - 1; ++t) {
@@ -556,10 +582,10 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                             fresh = v <= 0;
                         }
                         int cnt;
-                        if (wave_group(key, fresh, cnt)) atomicMin(&s.newid[key], p - P);
+                        if (wave_group(key, fresh, cnt)) atomicMin(gen(&s.newid[key]), p - P);
                         if (wave_group(c, valid, cnt)) {
                             if (direct) {
-                                atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p);
+                                atomicAdd(gen(&s.ncop[c]), cnt); atomicMin(gen(&s.firstc[c]), p);
                             } else {
                                 bool won;
                                 const int slot = ht_insert(sh.h2, c, won, 48);
@@ -577,7 +603,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                             const bool valid = p < P;
                             const int c = valid ? sidp[p] : 0;
                             int cnt;
-                            if (wave_group(c, valid, cnt)) { atomicAdd(&s.ncop[c], cnt); atomicMin(&s.firstc[c], p); }
+                            if (wave_group(c, valid, cnt)) { atomicAdd(gen(&s.ncop[c]), cnt); atomicMin(gen(&s.firstc[c]), p); }
                         }
                         __syncthreads();
                     }
@@ -782,7 +808,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             for (int p = tid; p < P; p += T) sh.lw[p] = 1.0;     // src/pmdi.jl:319
             __syncthreads();
             // ancestor of every slot after the conditional-SMC fix-up (slot 0 keeps particle 0)
-            int *ancp = a.pp_lds ? gen(sh.kv) : make_ks(a.ds[0], chain).kv;
+            const Dual<int> ancp = dual(a.pp_lds != 0, sh.kv, make_ks(a.ds[0], chain).kv);
             for (int p = tid; p < P; p += T) ancp[p] = (p == 0) ? 0 : (p <= js ? pstar_raw[p - 1] : pstar_raw[p]);
             __syncthreads();
             for (int k = 0; k < K; ++k) {                         // src/pmdi.jl:320-340
@@ -791,11 +817,11 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 const int D = d.D;
                 const int cur = sh.kcur[k];
                 const int oldmax = sh.kmaxid[k];
-                int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
-                int *sidp = a.pp_lds ? gen(sh.sid) : s.sid;
-                const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
-                const int *src = s.part[cur];
-                int *dst = s.part[cur ^ 1];
+                const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+                const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
+                const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
+                const gcint src = s.part[cur];
+                const gint dst = s.part[cur ^ 1];
                 // live marks, then old id -> new id, in LDS (the term buffer is idle) when the ids fit;
                 // otherwise the per-id scratch tables in global memory
                 const bool lm = oldmax + 1 <= 2 * a.terms_cap;
@@ -807,7 +833,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                     const int p = pb + tid;
                     if (p < P) {
                         const int an = ancp[p];
-                        sidp[p] = pidk[an];                       // (:323)
+                        sidp[p] = (int)pidk[an];                  // (:323)
                         int nn = 0;
                         for (; nn + 4 <= N; nn += 4) {            // four independent gathers in flight
                             const int v0 = src[nn * P + an], v1 = src[(nn + 1) * P + an], v2 = src[(nn + 2) * P + an], v3 = src[(nn + 3) * P + an];
@@ -823,7 +849,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                     }
                 }
                 __syncthreads();
-                for (int p = tid; p < P; p += T) pidk[p] = sidp[p];
+                for (int p = tid; p < P; p += T) pidk[p] = (int)sidp[p];
                 // sort(unique(particle)) ascending -> 1..U' (:329): scan of live marks
                 unsigned long long carry = 0;
                 for (int b = 0; b < oldmax; b += T) {
@@ -851,7 +877,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                         if (valid) { v = PMDI_NEWID(dst[nn * P + p]); dst[nn * P + p] = v; }
                         int cnt;
                         if (wave_group(v, valid, cnt)) {
-                            if (lhist) atomicAdd(gen(&hist[v]), cnt); else atomicAdd(&s.counts[v], cnt);
+                            if (lhist) atomicAdd(gen(&hist[v]), cnt); else atomicAdd(gen(&s.counts[v]), cnt);
                         }
                     }
                 }
@@ -881,9 +907,9 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                             const int nid = (it < nitems) ? PMDI_NEWID(id) : 0;
                             const bool mv = nid != 0 && nid != id;
                             double2 sb = make_double2(0, 0);
-                            if (mv) sb = s.sb[(size_t)id * D + q];
+                            if (mv) sb = ld2(s.sb, (size_t)id * D + q);
                             __syncthreads();
-                            if (mv) s.sb[(size_t)nid * D + q] = sb;
+                            if (mv) st2(s.sb, (size_t)nid * D + q, sb);
                         }
                     } else if (d.kind == K_CATEGORICAL) {
                         const long long itemsL = nitems * d.L;
@@ -1021,10 +1047,11 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     int i_next = order[n1 - 1];
     double nx = 0.0;          // register-staged observation row of the upcoming step
     int nxi = 0;
+    int ns0_next = s_in[i_next];   // ... and the reference trajectory's label there (dataset 0)
     {
         const DsetDev &d0 = a.ds[0];
         if (tid < d0.D) {
-            if (d0.kind == K_GAUSSIAN) nx = d0.xf[(size_t)i_next * d0.D + tid]; else nxi = d0.xi[(size_t)i_next * d0.D + tid];
+            if (d0.kind == K_GAUSSIAN) nx = glob(d0.xf)[(size_t)i_next * d0.D + tid]; else nxi = glob(d0.xi)[(size_t)i_next * d0.D + tid];
         }
     }
     for (long long pos = n1 - 1; pos < n && !failed; ++pos) {
@@ -1043,18 +1070,19 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             const int maxid = sh.kmaxid[k];
             const int ncls = sh.kncls[k];
             const int cur = sh.kcur[k];
-            int *part = s.part[cur];
-            int *pidk = a.pid_lds ? gen(sh.pid + (size_t)k * P) : s.pid;
-            int *sidp = a.pp_lds ? gen(sh.sid) : s.sid;
-            int *kvp = a.pp_lds ? gen(sh.kv) : s.kv;
+            const gint part = s.part[cur];
+            const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+            const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
+            const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
             const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
             const double *pik = gen(sh.pis + k * N);
-            const ClsList cl{gen(sh.cl_lead + k * PMDI_CLS_LDS), gen(sh.cl_val + k * PMDI_CLS_LDS), s.clslead, s.clsval, PMDI_CLS_LDS};
+            const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
             const int items = ncls * N;
             const bool small = items <= PMDI_ITEM_CAP;
             if (ncls != 1) lw_uniform = false;
 
             PH(1);
+            const int ns0_cur = ns0_next;
             // the observation row was fetched into registers during the previous step
             if (tid < D) {
                 if (d.kind == K_GAUSSIAN) sh.xs[tid] = nx; else ((int *)sh.xs)[tid] = nxi;
@@ -1079,7 +1107,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 }
             }
             for (int q = T + tid; q < D; q += T) {
-                if (d.kind == K_GAUSSIAN) sh.xs[q] = d.xf[(size_t)i * D + q]; else ((int *)sh.xs)[q] = d.xi[(size_t)i * D + q];
+                if (d.kind == K_GAUSSIAN) sh.xs[q] = glob(d.xf)[(size_t)i * D + q]; else ((int *)sh.xs)[q] = glob(d.xi)[(size_t)i * D + q];
             }
             if (small) lds_barrier(); else __syncthreads();
             const int nneed = small ? sh.misc[M_NEED] : maxid;
@@ -1100,21 +1128,21 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         const int id = small ? sh.need[j0 + il] : 1 + j0 + il;
                         const int cn = s.cn[id];
                         if (q == D) {   // the per-cluster prefix: gaussian_cluster.jl:38-40
-                            if (d.kind == K_GAUSSIAN) sh.term[il * RS + 2 * D] = (double)nflag * d.gtab[cn];
+                            if (d.kind == K_GAUSSIAN) sh.term[il * RS + 2 * D] = (double)nflag * glob(d.gtab)[cn];
                             continue;
                         }
                         if (!flk[q]) continue;
                         double ta = 0.0, tb = 0.0;
                         if (d.kind == K_GAUSSIAN) {
-                            gauss_terms(sh.xs[q], (double)cn, gauss_ml(cn, s.sb[(size_t)id * D + q]), ta, tb);
+                            gauss_terms(sh.xs[q], (double)cn, gauss_ml(cn, ld2(s.sb, (size_t)id * D + q)), ta, tb);
                         } else if (d.kind == K_CATEGORICAL) {
                             const int x = ((const int *)sh.xs)[q];
-                            ta = d.lhtab[d.maxcol[q] + 2 * cn];                 // log(nlevels_q + n)
+                            ta = glob(d.lhtab)[glob(d.maxcol)[q] + 2 * cn];                 // log(nlevels_q + n)
                             const int c = s.cnt[((size_t)id * D + q) * d.L + (x - 1)];
-                            tb = (cn == 0) ? d.lhtab[1] : d.lhtab[2 * c + 1];   // log(0.5 + counts)
+                            tb = (cn == 0) ? glob(d.lhtab)[1] : glob(d.lhtab)[2 * c + 1];   // log(0.5 + counts)
                         } else {
                             const int x = ((const int *)sh.xs)[q];
-                            ta = negbin_term(d.lgtab, cn, x, s.nbs[(size_t)id * D + q]);
+                            ta = negbin_term(glob(d.lgtab), cn, x, s.nbs[(size_t)id * D + q]);
                         }
                         sh.term[il * RS + 2 * q] = ta;
                         sh.term[il * RS + 2 * q + 1] = tb;
@@ -1161,7 +1189,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // wave; max / cumsum / normalise by shuffles.  The cumsum follows Julia's
             // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
             PH(4); FRESH_LANE_IDS();
-            double *cdfp = small ? gen(sh.cdf) : s.cdf;
+            const Dual<double> cdfp = dual(small, sh.cdf, s.cdf);
             {
                 const int G = 64 / N;
                 const int g = lane / N, nn = lane - g * N;
@@ -1248,8 +1276,9 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 if (kn == K) { kn = 0; in_ = i_next; have = pos + 1 < n; }
                 const DsetDev &dn = a.ds[kn];
                 if (have && tid < dn.D) {
-                    if (dn.kind == K_GAUSSIAN) nx = dn.xf[(size_t)in_ * dn.D + tid]; else nxi = dn.xi[(size_t)in_ * dn.D + tid];
+                    if (dn.kind == K_GAUSSIAN) nx = glob(dn.xf)[(size_t)in_ * dn.D + tid]; else nxi = glob(dn.xi)[(size_t)in_ * dn.D + tid];
                 }
+                if (have) ns0_next = s_in[(size_t)kn * n + in_];
             }
             if (small) {
                 for (int j = tid; j < nneed; j += T) { const int sl = sh.need_slot[j]; sh.h1.key[sl] = 0; sh.h1.a[sl] = 0; }
@@ -1258,45 +1287,108 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             bool fast = small && sh.khint[k] == 0;   // hint: the last steps chose too many distinct clusters for the LDS census
             bool converted = false;
             int nd = 0, nclone = 0, new_ncls = 0;
+            // -- C1: allocation draw (:251-265).  While drawing, the particles vote on whether the step is
+            // unanimous: one class, every particle draws the reference trajectory's label and holds the
+            // same cluster under it.  Then :266-310 has one outcome for all particles (one key, one
+            // chosen cluster with ncopies = P, cloned iff counts != P): no census, no ranks.
+            bool ustep = false;
             if (fast) {
-                for (int pb = 0; pb < P; pb += T) {
-                    const int p = pb + tid;
-                    const bool valid = p < P;
-                    int ns = 0, c = 0, kidx = 0;
-                    if (valid) {
-                        const int r = sh.slot_of[pidk[p]];
-                        const double *row = gen(sh.cdf + (size_t)r * (N + 2));
+                const int ns0 = ns0_cur;                                     // reference trajectory (:262), fetched a step ago
+                const int c0 = part[(size_t)ns0 * P];
+                int same = (ncls == 1) ? 1 : 0;
+                const bool one = ncls == 1;                                  // every particle reads CDF row 0
+                for (int pb0 = 0; pb0 < P; pb0 += 4 * T) {       // four particles per lane, stage by stage: their
+                    int ns_[4], c_[4], r_[4];                    // LDS chains and pool reads overlap
+                    double inc_[4], lw_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = pb0 + u * T + tid;
+                        r_[u] = (!one && p < P) ? sh.slot_of[pidk[p]] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = pb0 + u * T + tid;
+                        const double *row = gen(sh.cdf + (size_t)r_[u] * (N + 2));
                         const int hot = (int)row[N + 1];
-                        if (p != 0 && hot >= 0) {
+                        inc_[u] = row[N];
+                        lw_[u] = (p < P) ? sh.lw[p] : 0.0;
+                        int ns = 0;
+                        if (p == 0) {
+                            ns = ns0;
+                        } else if (hot >= 0) {
                             ns = hot;                                // one-hot CDF: no random number needed
-                        } else if (p != 0) {
-                            const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                        } else if (p < P) {
+                            const double u01 = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
                             // first label whose CDF exceeds u (:252-260); the CDF is non-decreasing, so
                             // that is the number of leading entries that do not exceed u
                             int t = 0;
                             for (; t + 4 <= N - 1; t += 4) {          // four LDS reads in flight
                                 const double a0 = row[t], a1 = row[t + 1], a2 = row[t + 2], a3 = row[t + 3];
-                                ns += ((a0 > u) ? 0 : 1) + ((a1 > u) ? 0 : 1) + ((a2 > u) ? 0 : 1) + ((a3 > u) ? 0 : 1);
+                                ns += ((a0 > u01) ? 0 : 1) + ((a1 > u01) ? 0 : 1) + ((a2 > u01) ? 0 : 1) + ((a3 > u01) ? 0 : 1);
                             }
-                            for (; t < N - 1; ++t) ns += (row[t] > u) ? 0 : 1;
-                        } else {
-                            ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
+                            for (; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
                         }
-                        sh.lw[p] += row[N];
-                        c = part[ns * P + p];                        // sstar_id (:264)
-                        kidx = r * N + ns;
-                        sidp[p] = kidx;
-                        sh.news[k * P + p] = (unsigned char)ns;
-                        s.sstar[(size_t)pos * P + p] = (unsigned char)ns;   // (:265)
+                        ns_[u] = ns;
+                        c_[u] = (p < P) ? part[ns * P + p] : 0;     // sstar_id (:264)
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int p = pb0 + u * T + tid;
+                        if (p < P) {
+                            sh.lw[p] = lw_[u] + inc_[u];
+                            sh.news[k * P + p] = (unsigned char)ns_[u];
+                            s.sstar[(size_t)pos * P + p] = (unsigned char)ns_[u];   // (:265)
+                            sidp[p] = r_[u] * N + ns_[u];
+                            kvp[p] = c_[u];
+                            same &= (ns_[u] == ns0 && c_[u] == c0) ? 1 : 0;
+                        }
+                    }
+                }
+                // what a unanimous step needs from the pool, fetched before the vote's barrier
+                const int key = (cl.val(0) - 1) * N + ns0;
+                int v = (a.q1 == 1 || ncls != 1) ? 0 : s.newid[key];         // (:266)
+                const bool freshk = v <= 0;
+                if (freshk) v = 1;                                           // curr_id += 1 (:267-269)
+                const bool needs = s.counts[c0] != P;                        // ncopies == counts ? (:286)
+                const int nnew = s.cn[c0] + 1;
+                ustep = __syncthreads_and(same) != 0;
+                if (ustep) {
+                    PH(13);
+                    const int tgt = needs ? maxid + 1 : c0;                  // (:290-292)
+                    nclone = needs ? 1 : 0;
+                    new_ncls = 1;
+                    if (maxid + nclone > cap) { failed = 1; break; }
+                    for (int p = tid; p < P; p += T) {
+                        pidk[p] = v;
+                        if (needs) part[(size_t)ns0 * P + p] = tgt;          // (:301-308)
+                    }
+                    if (tid == 0) {
+                        if (freshk && a.q1 == 0) s.newid[key] = v;
+                        if (needs) { s.counts[c0] -= P; s.counts[tgt] = P; } // (:293-294)
+                        s.cn[tgt] = nnew;
+                        cl.set(0, 0, v);
+                    }
+                    stats_update_all<T>(d, s, flk, gen(sh.xs), 1, D, tid, [&](int, int &src, int &dst, int &nn) {
+                        src = c0; dst = tgt; nn = nnew;
+                    });
+                }
+            }
+            if (!ustep) {
+            if (fast) {
+                // -- C2: census of the chosen clusters and of the touched (class, label) keys
+                for (int pb = 0; pb < P; pb += T) {
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    int c = 0, kidx = 0;
+                    if (valid) { c = kvp[p]; kidx = sidp[p]; }
                     const unsigned long long vmask = __ballot(valid);
-                    const int k0 = __shfl(kidx, 0), c0 = __shfl(c, 0);
+                    const int k0 = __shfl(kidx, 0), c0w = __shfl(c, 0);
                     int slot = -1;
-                    if (__all(!valid || (kidx == k0 && c == c0))) {     // the whole wave agrees: one lane speaks
+                    if (__all(!valid || (kidx == k0 && c == c0w))) {     // the whole wave agrees: one lane speaks
                         if (lane == 0 && valid) {
                             atomicMin(gen(&sh.ktab_minp[k0]), p);
                             bool won;
-                            slot = ht_insert(sh.h2, c0, won, 48);
+                            slot = ht_insert(sh.h2, c0w, won, 48);
                             if (slot < 0) sh.misc[M_OVF] = 1;
                             else { atomicAdd(gen(&sh.h2.a[slot]), __popcll(vmask)); atomicMin(gen(&sh.h2.b[slot]), p); }
                         }
@@ -1446,6 +1538,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 nclone = sh.misc[M_NCLONE];
                 new_ncls = sh.misc[M_NCLS];
             }
+            }
             if (fast) ++st_fast; else if (converted) ++st_conv; else ++st_slow;
             st_nops += maxid;                     // src/__pmdi.jl:187
             st_sumcls += ncls;
@@ -1477,12 +1570,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 
         // -- calc_ESS (src/misc.jl:15-25).  If every log-weight is the same number the sums are
         // exact (P ones): ESS == P, no resampling; skip the exps.
-        if (!lw_uniform) {
-            const double l0 = sh.lw[0];
-            int same = 1;
-            for (int p = tid; p < P; p += T) same &= (sh.lw[p] == l0) ? 1 : 0;
-            lw_uniform = __syncthreads_and(same) != 0;
-        }
+        // (once the log-weights differ they stay different until a resampling resets them)
         double ess = (double)P;
         bool resample = false;
         double mx = 0.0;
@@ -1576,6 +1664,7 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
     if (T == 1024) fn = k1 ? (const void *)pmdi_sweep_kernel<1024, 4, true> : (const void *)pmdi_sweep_kernel<1024, 4, false>;
     else if (T == 512 && two) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 4, true> : (const void *)pmdi_sweep_kernel<512, 4, false>;
     else if (T == 512) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 2, true> : (const void *)pmdi_sweep_kernel<512, 2, false>;
+    else if (T == 128) fn = k1 ? (const void *)pmdi_sweep_kernel<128, 2, true> : (const void *)pmdi_sweep_kernel<128, 2, false>;
     else if (T == 256) fn = k1 ? (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, true> : (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, false>;
     else return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -13,7 +13,7 @@ block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 w = workloads.make("cfg2", scale)
 g = DeviceGibbsK1(w["data"][0], "gaussian", w["N"], w["P"], chains, seed=1000, block_threads=block)
-names = ["setup+prefix", "stage+needlist", "terms", "sums", "cdf", "C:draw+census", "D1:keys+firsts", "D2:ranks", "E:apply+stats", "phi+ess+looptop", "resample", "final", "slow:draw/census", "slow:stats"]
+names = ["setup+prefix", "stage+needlist", "terms", "sums", "cdf", "C:draw+census", "D1:keys+firsts", "D2:ranks", "E:apply+stats", "phi+ess+looptop", "resample", "final", "slow:draw/census", "slow:stats|unanimous"]
 for it in range(warm + 3):
     t0 = time.perf_counter(); g.iteration(); st = g.check(); dt = time.perf_counter() - t0
     ids = st[:, 0] / (g.n - g.n1 + 1)
