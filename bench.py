@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--chains", type=int, default=2048, help="independent chains per GPU (one workgroup each)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n of the workload (debug only)")
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--groups", type=int, default=1,
+                    help="drive the chains of a GPU as this many independent groups, each on its own stream "
+                         "(measured: 2 groups 15%% slower, 4 groups 40%% slower than 1 -- a launch is bounded by its "
+                         "slowest chain and concurrent launches slow each other's slow chains down)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
     args = ap.parse_args()
@@ -80,37 +84,67 @@ def main():
 
     w = workloads.make("cfg2", args.scale)
     n, N, P, C = w["n"], w["N"], w["P"], args.chains
-    g = DeviceGibbsK1(w["data"][0], "gaussian", N, P, C, seed=1000 + rank, device=local_rank,
-                      block_threads=args.block, rho=w["rho"])
+    NG = max(1, min(args.groups, C))
+    Cg = [C // NG + (1 if gi < C % NG else 0) for gi in range(NG)]
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(NG)]
+    groups = []
+    for gi in range(NG):
+        with torch.cuda.stream(streams[gi]):
+            groups.append(DeviceGibbsK1(w["data"][0], "gaussian", N, P, Cg[gi], seed=1000 + 7919 * rank + 104729 * gi,
+                                        device=local_rank, block_threads=args.block, rho=w["rho"]))
+    g = groups[0]
     n_s = n - g.n1 + 1
 
+    def all_stats():
+        return np.concatenate([gr.check() for gr in groups], axis=0)
+
     for w_it in range(args.warmup):
-        g.iteration()
+        for gi, gr in enumerate(groups):
+            with torch.cuda.stream(streams[gi]):
+                gr.iteration()
         if os.environ.get("PMDI_BENCH_VERBOSE") and rank == 0:
-            st = g.check()
+            st = all_stats()
             print(f"warmup {w_it}: ids/step {st[:, 0].mean() / n_s:.1f} classes/step {st[:, 4].mean() / n_s:.2f} "
                   f"resamples {st[:, 1].mean():.1f}", file=sys.stderr, flush=True)
-    g.check()
+    all_stats()
 
-    samples = torch.empty((args.steps, C, n), dtype=torch.uint8, device=g.dev)
+    samples = [torch.empty((args.steps, Cg[gi], n), dtype=torch.uint8, device=g.dev) for gi in range(NG)]
+    base = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    base.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        g.iteration(time_kernel=True)
-        samples[k].copy_(g.s)                      # retained allocation sample of this iteration
-        g.finish_timing()
+        for gi, gr in enumerate(groups):
+            with torch.cuda.stream(streams[gi]):
+                gr.iteration(time_kernel=True)          # waits for this group's previous sweep only
+                samples[gi][k].copy_(gr.s)              # retained allocation sample of this iteration
+    torch.cuda.synchronize()
     if dist is not None:
-        gathered = torch.empty((world,) + tuple(samples.shape), dtype=torch.uint8, device=g.dev)
-        dist.all_gather_into_tensor(gathered, samples)      # RCCL over xGMI: PSM input
+        allsamp = torch.cat(samples, dim=1)
+        gathered = torch.empty((world,) + tuple(allsamp.shape), dtype=torch.uint8, device=g.dev)
+        dist.all_gather_into_tensor(gathered, allsamp)      # RCCL over xGMI: PSM input
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    stats = g.check()
+    stats = all_stats()
+    # per-launch durations and the time at least one sweep launch was running (HIP events on the launch streams)
+    ivals = sorted((base.elapsed_time(e0), base.elapsed_time(e1)) for gr in groups for (e0, e1) in gr.events)
+    launch_ms = [b - a for a, b in ivals]
+    busy_ms, cur_a, cur_b = 0.0, None, None
+    for a, b in ivals:
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                busy_ms += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    busy_ms += (cur_b - cur_a) if cur_b is not None else 0.0
 
     t = torch.tensor([dt], dtype=torch.float64, device=g.dev)
     if dist is not None:
@@ -120,15 +154,15 @@ def main():
     out = None
     if rank == 0:
         total_iters = args.steps * C * world
-        kernel_ms = float(np.mean(g.kernel_ms))
+        kernel_ms = float(np.mean(launch_ms))                     # one launch = the chains of one group
         bytes_unit = workloads.algorithmic_bytes_per_obs_particle(w["kinds"], w["D"], N)
-        alg_bytes_launch = float(bytes_unit) * n_s * P * C
+        alg_bytes_launch = float(bytes_unit) * n_s * P * (C / NG)
         achieved = alg_bytes_launch / (kernel_ms * 1e-3)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):       # PMC-measured HBM bytes per launch of this same command (profiles/README.md)
             tj = json.load(open(tpath))
-            if tj.get("chains_per_gpu") == C and tj.get("workload") == "cfg2" and args.scale == 1.0:
+            if tj.get("chains_per_gpu") == C and tj.get("groups", 1) == NG and tj.get("workload") == "cfg2" and args.scale == 1.0:
                 traffic = tj["hbm_bytes_per_launch"]
         out = {
             "metric": "Gibbs iters/sec (and obs·particles/sec) at 1/2/4/8 GPUs vs CPU ref",
@@ -140,11 +174,14 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "cfg2: 3-mixture Gaussian 10000x50, K=1, N=20, P=1024, rho=0.25"
                        if args.scale == 1.0 else f"cfg2 scaled n={n}",
-                       "chains_per_gpu": C, "block_threads": g.sw.block_threads, "lds_bytes_per_chain": g.sw.lds_bytes,
+                       "chains_per_gpu": C, "chain_groups": NG, "chains_per_launch": C // NG,
+                       "block_threads": g.sw.block_threads, "lds_bytes_per_chain": g.sw.lds_bytes,
                        "swept_obs_per_iter": n_s, "parallelism": f"chains x{world}"},
             "obs_particles_per_sec": total_iters * n_s * P / dt,
             "sweep_kernel_ms": kernel_ms,
-            "sweep_only_iters_per_sec": C * world / (kernel_ms * 1e-3),
+            "sweep_busy_ms_per_step": busy_ms / args.steps,
+            "launch_concurrency": float(np.sum(launch_ms)) / busy_ms if busy_ms > 0 else None,
+            "sweep_only_iters_per_sec": args.steps * C * world / (busy_ms * 1e-3),
             "median_chain_iters_per_sec_hint": "see profiles/README.md (per-chain latency distribution)",
             "sweep_stats_last": {"ids_per_step": float(stats[:, 0].mean()) / n_s,
                                  "classes_per_step": float(stats[:, 4].mean()) / n_s,

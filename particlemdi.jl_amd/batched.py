@@ -93,6 +93,7 @@ class DeviceGibbsK1:
         self.gen.manual_seed(seed + 12345)
         self.it = 0
         self.kernel_ms = []
+        self.events = []          # (start, end) HIP events of every timed sweep, for interval arithmetic
         self._ones = torch.ones((n_chains, self.n), dtype=torch.float64, device=self.dev)
 
     def iteration(self, time_kernel=False):
@@ -118,6 +119,7 @@ class DeviceGibbsK1:
         if time_kernel:
             e1.record(stream)
             self._pending = (e0, e1)
+            self.events.append((e0, e1))
         self.s, self.s_next = self.s_next, self.s      # s = sstar[p_star,:,:] (:373); align_labels! is a no-op for K=1
 
     def finish_timing(self):

@@ -106,15 +106,16 @@ struct pmdi_handle {
     bool split = false;
     int l_terms_cap = 0, l_pid_lds = 0, l_pp_lds = 0;
     long long light_ids = 0;
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    int very_heavy = 0;          // the first `very_heavy` heavy chains of the launch order get a CU each (256-register build)
     bool phase_on = false;
     hipStream_t stream = nullptr;
     DsetDev ds[PMDI_KMAX_I]{};
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_group, d_cost, d_lorder;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder;
     bool have_order = false;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
@@ -182,10 +183,22 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
         HIP_TRY(hipEventRecord(h->ev_fork, st));
         a.group_flag = (const unsigned char *)h->d_group.p;
         a.group_sel = 1;
+        const int vh = h->very_heavy < C ? h->very_heavy : C;
+        if (vh > 0) {
+            // the heaviest chains bound the launch: they get the 256-register build, one CU each
+            SweepArgs av = a;
+            av.two_per_cu = 0; av.rank_lo = 0; av.rank_hi = vh;
+            HIP_TRY(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
+            e = pmdi_launch_sweep(av, (SweepArgs *)h->d_args3.p, vh, h->T, h->stream3);
+            if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (heaviest chains): %s", hipGetErrorString(e));
+            HIP_TRY(hipEventRecord(h->ev_join3, h->stream3));
+        }
+        a.rank_lo = vh; a.rank_hi = C;
         e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, st);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (heavy group): %s", hipGetErrorString(e));
+        if (vh > 0) HIP_TRY(hipStreamWaitEvent(st, h->ev_join3, 0));
         SweepArgs al = a;
-        al.group_sel = 0;
+        al.group_sel = 0; al.rank_lo = 0; al.rank_hi = C;
         al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds;
         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         e = pmdi_launch_sweep(al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
@@ -217,11 +230,13 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_group, &h->d_cost, &h->d_lorder,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->stream3) { (void)hipStreamSynchronize(h->stream3); (void)hipStreamDestroy(h->stream3); }
+    if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     delete h;
@@ -376,10 +391,17 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds)) h->split = false;
         }
         if (h->split) {
-            if (hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+            // the slow chains bound the launch, so their workgroups must not queue behind the many
+            // light ones: light launch on a low-priority stream, heaviest chains on a high-priority one
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // (least, greatest); greatest is the smaller number
+            if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+                hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+                hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess)
                 return bail(fail(PMDI_E_DEVICE, "stream/event creation failed"));
+            h->very_heavy = (h->T == 512 && h->two_per_cu) ? env_int("PMDI_VERY_HEAVY", 128) : 0;
         }
     }
     const int C = cfg->n_chains;
@@ -388,7 +410,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
         (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
         (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
-        (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
+        (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
         return bail(rc);
     if (hipMemset(h->d_group.p, 1, (size_t)C) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));   // first sweep: every chain is heavy
 

@@ -90,6 +90,7 @@ struct SweepArgs {
     const int *chain_order;     // [n_chains] workgroup b sweeps chain chain_order[b] (heaviest first), or null
     const unsigned char *group_flag;  // [n_chains] 1 = heavy chain (many private clusters), 0 = light; or null
     int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
+    int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
 };
 
 struct ClusterBatchArgs {

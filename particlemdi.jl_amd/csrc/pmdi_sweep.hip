@@ -462,15 +462,15 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
 // deepcopy + cluster_add! of every distinct chosen cluster (src/pmdi.jl:297,:300): lanes =
 // (cluster, feature).  item(j, src, dst, nnew) names the j-th chosen cluster.  The clusters of a
 // chain that still carries hundreds of private copies are spread over megabytes of pool, so
-// every statistic is an HBM miss: a lane fetches several of them before it touches the first.
-template <int T, class Item>
+// every statistic is an HBM miss: a lane fetches U of them before it touches the first (U = 4; 8 in
+// the 256-register wide build -- in the 128-register build 8 spills and is slower).
+template <int T, int U, class Item>
 __device__ __forceinline__ void stats_update_all(const DsetDev &d, const KS &s, const unsigned char *flk, const double *xs,
                                                  int nd, int D, int tid, Item item)
 {
     const int total = nd * D;
     int it = tid;
     if (d.kind == K_GAUSSIAN) {
-        constexpr int U = 4;   // 8 spills in the 128-register build and is slower
         for (; it + (U - 1) * T < total; it += U * T) {
             int src[U], dst[U], nnew[U], q[U];
             double2 sb[U];
@@ -501,7 +501,7 @@ __device__ __forceinline__ void stats_update_all(const DsetDev &d, const KS &s, 
 // One (observation, dataset) step on the fallback path: per-particle class keys, ballot scans,
 // per-id tables in global memory.  `converted`: the fast path already drew the allocations but
 // its LDS census overflowed.  Results (clones, classes, pool overflow) go back through sh.misc.
-template <int T>
+template <int T, int WPS>
 __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int k, int i, long long pos, bool small,
                                         bool converted, int maxid, int ncls, long long &ph_last, int &ph_cur)
 {
@@ -705,7 +705,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
                     }
                     PHS(13);
-                    stats_update_all<T>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
+                    stats_update_all<T, (T >= 512 && WPS <= 2) ? 8 : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
                         if (j < PMDI_DL_LDS) { src = sh.dl[j]; dst = sh.dl[PMDI_DL_LDS + j]; nnew = sh.dl[2 * PMDI_DL_LDS + j]; }
                         else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
                     });
@@ -1014,7 +1014,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 {
     PMDI_PREAMBLE_K(K1);
     // two launches share the chains of a sweep (heavy: wide workgroups, light: narrow ones)
-    if (a.group_flag && (int)a.group_flag[chain] != a.group_sel) return;
+    if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || (int)blockIdx.x < a.rank_lo || (int)blockIdx.x >= a.rank_hi)) return;
 
     const long long t_start = clock64();
     long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
@@ -1368,7 +1368,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         s.cn[tgt] = nnew;
                         cl.set(0, 0, v);
                     }
-                    stats_update_all<T>(d, s, flk, gen(sh.xs), 1, D, tid, [&](int, int &src, int &dst, int &nn) {
+                    stats_update_all<T, (T >= 512 && WPS <= 2) ? 8 : 4>(d, s, flk, gen(sh.xs), 1, D, tid, [&](int, int &src, int &dst, int &nn) {
                         src = c0; dst = tgt; nn = nnew;
                     });
                 }
@@ -1524,7 +1524,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         pidk[p] = sh.ktab_val[sidp[p]];
                     }
                 }
-                stats_update_all<T>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
+                stats_update_all<T, (T >= 512 && WPS <= 2) ? 8 : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
                     src = sh.fl_p[j]; dst = sh.fl_tgt[j]; nnew = sh.fl_nnew[j];
                 });
                 for (int j = tid; j < nk; j += T) sh.ktab_minp[sh.klist[j]] = PMDI_INF_I;
@@ -1533,7 +1533,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 for (int j = tid; j < nf; j += T) { const int sl = sh.fl_slot[j]; sh.h2.key[sl] = 0; sh.h2.a[sl] = 0; sh.h2.b[sl] = PMDI_INF_I; }
                 if (tid == 0) { sh.misc[M_NK] = 0; sh.misc[M_NF] = 0; }
             } else {
-                sweep_slow<T>(ap, k, i, pos, small, converted, maxid, ncls, ph_last, ph_cur);
+                sweep_slow<T, WPS>(ap, k, i, pos, small, converted, maxid, ncls, ph_last, ph_cur);
                 if (sh.misc[M_FAIL]) { failed = 1; break; }
                 nclone = sh.misc[M_NCLONE];
                 new_ncls = sh.misc[M_NCLS];
