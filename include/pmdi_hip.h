@@ -171,6 +171,12 @@ int pmdi_calc_logmarginal(pmdi_cluster_batch *cb, double *out /* B x D_k, row pe
  * number of doubles per cluster in *stride */
 int pmdi_cluster_stats(pmdi_cluster_batch *cb, double *out, int64_t *stride);
 
+/* Label occupancy of device-resident allocations: counts[chain][k][label] = #{i : s[chain][k][i] == label}
+ * (0-based int32 labels, layout of pmdi_sweep_device's s_out).  This is countn(s[:, k], n) of
+ * update_gamma! (src/update_hypers.jl:72, src/misc.jl countn) for every label at once, so that
+ * only n_chains*K*N integers cross PCIe per iteration.  Asynchronous on `stream`. */
+int pmdi_label_counts_device(pmdi_handle *h, const int32_t *s, int32_t *counts, void *stream);
+
 /* Debug: per-phase shader-clock totals of the last sweep (lane 0 of the chain's workgroup);
  * only when the environment variable PMDI_PHASE_TIMERS was set at pmdi_create. */
 int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);

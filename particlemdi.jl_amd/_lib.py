@@ -28,7 +28,7 @@ EXPORTS = [
     "pmdi_sweep_device", "pmdi_feature_select", "pmdi_export_state", "pmdi_clusters_new",
     "pmdi_clusters_free", "pmdi_cluster_add", "pmdi_calc_logprob", "pmdi_calc_logmarginal",
     "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L", "pmdi_phase_timers",
-    "pmdi_block_threads", "pmdi_lds_bytes", "pmdi_chain_costs",
+    "pmdi_block_threads", "pmdi_lds_bytes", "pmdi_chain_costs", "pmdi_label_counts_device",
 ]
 
 
@@ -127,6 +127,8 @@ def lib():
     L.pmdi_block_threads.argtypes = [vp]
     L.pmdi_lds_bytes.restype = i64
     L.pmdi_lds_bytes.argtypes = [vp]
+    L.pmdi_label_counts_device.restype = C.c_int
+    L.pmdi_label_counts_device.argtypes = [vp, vp, vp, vp]
     L.pmdi_chain_costs.restype = C.c_int
     L.pmdi_chain_costs.argtypes = [vp, vp]
     L.pmdi_phase_timers.restype = C.c_int
@@ -174,6 +176,7 @@ class Sweeper:
                 xi = np.asfortranarray(x, dtype=np.int64)
                 self._keep.append(xi)
                 ds[k].xi = xi.ctypes.data_as(C.POINTER(C.c_int64))
+        self.device = int(device)
         cfg = _Config(ABI_VERSION, device, self.K, self.N, self.P, self.C, self.n, int(seed),
                       q1_mode, q2_mode, int(pool_cap), int(block_threads), 0)
         h = C.c_void_p()
@@ -244,6 +247,19 @@ class Sweeper:
         mx = np.zeros(K, dtype=np.int64)
         _check(lib().pmdi_export_state(self.h, int(chain), _ptr(particle), _ptr(counts), _ptr(cn), _ptr(mx)))
         return {"particle": particle, "counts": counts, "cluster_n": cn, "max_id": mx}
+
+    def label_counts(self, s):
+        """countn for every label (src/update_hypers.jl:72): s is (n_chains, K, n), 1-based labels as in
+        the reference; returns (n_chains, K, N) int64 occupancies computed on the device."""
+        import torch
+        s0 = np.ascontiguousarray(np.asarray(s).reshape(self.C, self.K, self.n) - 1, dtype=np.int32)
+        dev = torch.device("cuda", self.device)
+        ds = torch.from_numpy(s0).to(dev)
+        out = torch.zeros((self.C, self.K, self.N), dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev)
+        _check(lib().pmdi_label_counts_device(self.h, C.c_void_p(ds.data_ptr()), C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(st.cuda_stream)))
+        return out.cpu().numpy().astype(np.int64)
 
     def chain_costs(self):
         out = np.zeros(self.C, dtype=np.int64)

@@ -94,7 +94,7 @@ class DeviceGibbsK1:
         self.it = 0
         self.kernel_ms = []
         self.events = []          # (start, end) HIP events of every timed sweep, for interval arithmetic
-        self._ones = torch.ones((n_chains, self.n), dtype=torch.float64, device=self.dev)
+        self.counts = torch.zeros((n_chains, N), dtype=torch.int32, device=self.dev)
 
     def iteration(self, time_kernel=False):
         torch = self.torch
@@ -102,11 +102,11 @@ class DeviceGibbsK1:
         # shuffle!(order_obs) per chain (src/pmdi.jl:172), on the device
         self.order.copy_(torch.argsort(torch.rand((self.C, self.n), device=self.dev, generator=self.gen), dim=1))
         # label occupancy for update_gamma! (countn, update_hypers.jl:73)
-        counts = torch.zeros((self.C, self.N), dtype=torch.float64, device=self.dev)
-        counts.scatter_add_(1, self.s.long(), self._ones)
-        Pi = self.hy.step(counts.cpu().numpy())
-        self.Pi.copy_(torch.from_numpy(np.ascontiguousarray(Pi)))
         stream = torch.cuda.current_stream(self.dev)
+        _check(lib().pmdi_label_counts_device(self.sw.h, C.c_void_p(self.s.data_ptr()), C.c_void_p(self.counts.data_ptr()),
+                                              C.c_void_p(stream.cuda_stream)))
+        Pi = self.hy.step(self.counts.cpu().numpy().astype(np.float64))
+        self.Pi.copy_(torch.from_numpy(np.ascontiguousarray(Pi)))
         if time_kernel:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)

@@ -496,6 +496,15 @@ int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const i
     return PMDI_OK;
 }
 
+int pmdi_label_counts_device(pmdi_handle *h, const int32_t *s, int32_t *counts, void *stream)
+{
+    if (!h || !s || !counts) return fail(PMDI_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipError_t e = pmdi_launch_label_counts(s, counts, h->cfg.n_chains * h->cfg.K, h->cfg.n, h->cfg.N, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "label-count launch: %s", hipGetErrorString(e));
+    return PMDI_OK;
+}
+
 int pmdi_sweep(pmdi_handle *h, int64_t iter, const int64_t *s_in, const int64_t *order_obs, int64_t n1,
                const double *Pi, const double *Phi, const uint8_t *feature_flag, double lw_init, int64_t *s_out,
                double *logweight, int64_t *p_star, pmdi_sweep_stats *stats, double *trace)

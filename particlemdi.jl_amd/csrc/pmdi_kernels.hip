@@ -234,6 +234,28 @@ hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_
     return hipGetLastError();
 }
 
+// countn (src/misc.jl) for all labels of one (chain, dataset) row of allocations: LDS histogram
+__global__ void __launch_bounds__(256) label_count_kernel(const int *__restrict__ s, int *__restrict__ counts, long long n, int N)
+{
+    __shared__ int hist[64];   // N <= 64 (pmdi_create)
+    const int row = blockIdx.x;
+    for (int l = threadIdx.x; l < N; l += blockDim.x) hist[l] = 0;
+    __syncthreads();
+    const int *sr = s + (size_t)row * n;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const int v = sr[i];
+        if (v >= 0 && v < N) atomicAdd(&hist[v], 1);
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < N; l += blockDim.x) counts[(size_t)row * N + l] = hist[l];
+}
+
+hipError_t pmdi_launch_label_counts(const int *s, int *counts, int n_rows, long long n, int N, hipStream_t stream)
+{
+    hipLaunchKernelGGL(label_count_kernel, dim3(n_rows), dim3(256), 0, stream, s, counts, n, N);
+    return hipGetLastError();
+}
+
 hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream)
 {
     int Lmax = 1;

@@ -105,3 +105,17 @@ def test_empty_cluster_is_prior_predictive(O, mixed):
             assert np.allclose(got, want, rtol=RTOL)
         else:
             assert (got == want).all()
+
+
+@pytest.mark.gpu
+def test_label_counts_on_device(pkg):
+    # countn(s[:, k], n) for every label (src/update_hypers.jl:72) == numpy bincount
+    rng = np.random.default_rng(5)
+    n, N, K, Cn = 1237, 9, 2, 3
+    data = [rng.normal(size=(n, 2)), rng.normal(size=(n, 3))]
+    sw = pkg.Sweeper(data, ["gaussian", "gaussian"], N, 8, n_chains=Cn, seed=1)
+    s = rng.integers(1, N + 1, size=(Cn, K, n))
+    s[0, 0, :] = 4                                      # one label holds everything
+    got = sw.label_counts(s)
+    want = np.stack([[np.bincount(s[c, k] - 1, minlength=N) for k in range(K)] for c in range(Cn)])
+    assert got.shape == (Cn, K, N) and (got == want).all()
