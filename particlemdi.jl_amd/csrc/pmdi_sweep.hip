@@ -724,9 +724,17 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
 
 // draw_partstar (src/misc.jl:27-47), gather and compact renumbering (src/pmdi.jl:318-340)
 template <int T>
-__device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ ap, long long pos, double mx)
+__device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ ap, long long pos, double mx,
+                                                  long long &ph_last, int &ph_cur)
 {
     PMDI_PREAMBLE;
+#define PHR(i_)                                                                 \
+    do {                                                                        \
+        if (a.phase && tid == 0) {                                              \
+            const long long t_ = clock64();                                     \
+            sh.ph[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_);         \
+        }                                                                       \
+    } while (0)
             // draw_partstar (src/misc.jl:27-47)
             const double u01 = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
             const double usl = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
@@ -753,7 +761,30 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 for (; i < i1 + nn; ++i) { s_ = s_ + wb[i]; wb[i] = s_; }
                 sh.leaf_tot[tid] = s_;
             }
-            if (tid == T - 64) {                                  // u += 1/particles by repeated addition (:34)
+            const bool p_pow2 = (P & (P - 1)) == 0;
+            if (p_pow2) {
+                // u += 1/particles by repeated addition (:34), in parallel and still bit-exact: h = 1/P is a
+                // power of two, so inside a binade [2^e, 2^(e+1)) every u + h is exact (h is a multiple of
+                // ulp(u)); only the additions that cross into the next binade round.  Each lane replays the
+                // crossings (about ten of them) and jumps over the exact runs in between.
+                const double h = 1.0 / (double)P;
+                for (int j = tid; j < P; j += T) {
+                    double u = u01 / (double)P;
+                    int done = 0;
+                    while (done < j) {
+                        int e;
+                        (void)frexp(u, &e);                          // u in [2^(e-1), 2^e)
+                        const double B = ldexp(1.0, e);
+                        const double x = (B - u) * (double)P;        // exact: B - u (same binade) and the power-of-two scale
+                        double m = floor(x);
+                        if (m == x) m -= 1.0;                        // largest m with u + m*h < B
+                        if (m > (double)(j - done)) m = (double)(j - done);
+                        if (m >= 1.0) { u = u + m * h; done += (int)m; }      // exact run inside the binade
+                        if (done < j) { u = u + h; done += 1; }               // the crossing step rounds like the loop's
+                    }
+                    usc[j] = u;
+                }
+            } else if (tid == T - 64) {                           // general P: the additions round, one lane replays them
                 double u = u01 / (double)P;
                 const double h = 1.0 / (double)P;
                 usc[0] = u;
@@ -872,12 +903,23 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
                     const bool valid = p < P;
-                    for (int nn = 0; nn < N; ++nn) {
-                        int v = 0;
-                        if (valid) { v = PMDI_NEWID(dst[nn * P + p]); dst[nn * P + p] = v; }
-                        int cnt;
-                        if (wave_group(v, valid, cnt)) {
-                            if (lhist) atomicAdd(gen(&hist[v]), cnt); else atomicAdd(gen(&s.counts[v]), cnt);
+                    for (int nn0 = 0; nn0 < N; nn0 += 4) {            // four labels per round: their reads overlap
+                        int v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = (valid && nn0 + u < N) ? dst[(nn0 + u) * P + p] : 0;
+                        if (moves) {                                   // else every live id keeps its number
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (valid && nn0 + u < N) { v[u] = PMDI_NEWID(v[u]); dst[(nn0 + u) * P + p] = v[u]; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            if (nn0 + u < N) {
+                                int cnt;
+                                if (wave_group(v[u], valid, cnt)) {
+                                    if (lhist) atomicAdd(gen(&hist[v[u]]), cnt); else atomicAdd(gen(&s.counts[v[u]]), cnt);
+                                }
+                            }
                         }
                     }
                 }
@@ -943,6 +985,8 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 if (tid == 0) { sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1; }
                 __syncthreads();
             }
+    PHR(10);
+#undef PHR
 }
 
 // particle pick (src/pmdi.jl:345-350), s = sstar[p_star,:,:] (:373), counters
@@ -1588,7 +1632,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         if (resample) {
             PH(10);
             ++st_nres;
-            sweep_resample<T>(ap, pos, mx);
+            sweep_resample<T>(ap, pos, mx, ph_last, ph_cur);
             lw_uniform = true;
         }
 
