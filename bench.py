@@ -29,15 +29,15 @@ import __graft_entry__ as G  # noqa: E402
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 
 
-def cpu_baseline(w, warm, timed):
+def cpu_baseline(w, warm, timed, seed=5):
     """The oracle (a single-threaded port of the reference's loop, reference-cost bookkeeping
     kept) timed on this box's host cores for the same workload, one chain, 1 core."""
     O = G.load_oracle()
     from particlemdi_jl_amd.hypers import HyperState
     n, N, P = w["n"], w["N"], w["P"]
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(seed - 4)
     hy = HyperState(n, N, 1, rng)
-    orc = O.Oracle(w["data"], w["kinds"], N, P, seed=5, faithful_cost=1)
+    orc = O.Oracle(w["data"], w["kinds"], N, P, seed=seed, faithful_cost=1)
     order = np.arange(1, n + 1)
     n1 = int(np.floor(w["rho"] * n))
     secs = []
@@ -48,8 +48,30 @@ def cpu_baseline(w, warm, timed):
         hy.s[:] = r["s"]
         if it > warm:
             secs.append(r["stats"]["seconds"])
+        if seed == 5:
+            print(f"[bench] cpu baseline iteration {it}/{warm + timed}: {r['stats']['seconds']:.2f} s", file=sys.stderr, flush=True)
     orc.close()
     return float(np.mean(secs)), secs
+
+
+def _cpu_worker(args):
+    scale, warm, timed, seed = args
+    sys.path.insert(0, ROOT)
+    G.load_package()
+    from particlemdi_jl_amd import workloads
+    w = workloads.make("cfg2", scale)
+    sec, _ = cpu_baseline(w, warm, timed, seed)
+    return sec
+
+
+def cpu_baseline_all_cores(scale, warm, timed):
+    """the all-cores figure -- one independent chain per host core, what a user of the
+    single-threaded reference could do with `julia -p`.  Returns (aggregate iters/s, cores)."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        secs = pool.map(_cpu_worker, [(scale, warm, timed, 5 + c) for c in range(cores)])
+    return float(sum(1.0 / x for x in secs)), cores
 
 
 def main():
@@ -66,6 +88,7 @@ def main():
                          "slowest chain and concurrent launches slow each other's slow chains down)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
+    ap.add_argument("--cpu-all", action="store_true", help="also time one oracle chain per host core (SURVEY 8d all-cores figure; minutes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,12 +221,18 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
+        print(f"[bench] GPU part done: {out['value']:.1f} iters/s", file=sys.stderr, flush=True)
         if not args.no_cpu:
             sec, secs = cpu_baseline(w, 4, args.cpu_iters)
             out["cpu_baseline"] = {"value": 1.0 / sec, "unit": "Gibbs iters/s (sweep only, one chain)",
                                    "cores": 1, "kind": "port",
                                    "sample": f"oracle sweep, same workload, {args.cpu_iters} iterations after 4 warm-up "
                                              f"iterations ({sum(secs):.1f} s of CPU work)"}
+            if args.cpu_all:
+                agg, cores = cpu_baseline_all_cores(args.scale, 4, max(4, args.cpu_iters // 3))
+                out["cpu_baseline_all_cores"] = {"value": agg, "unit": "Gibbs iters/s (sweep only, one chain per core, aggregate)",
+                                                 "cores": cores, "kind": "port",
+                                                 "sample": f"{cores} oracle processes at once, {max(4, args.cpu_iters // 3)} iterations each after 4 warm-up"}
         print(json.dumps(out))
 
 
