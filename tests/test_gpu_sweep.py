@@ -137,6 +137,38 @@ def test_chains_are_independent_and_seeded(pkg, O):
         assert r["stats"][c]["n_operations"] == o["stats"]["n_operations"]
 
 
+def test_three_launch_groups_give_the_same_chains(pkg, O, monkeypatch):
+    """Automatic width (P > 256): a sweep is split into a heaviest / heavy / light launch by what the
+    chains' previous sweep looked like.  With thresholds that spread these chains over all three
+    launches, every chain must still equal its single-chain oracle run, iteration after iteration."""
+    thr = 400
+    monkeypatch.setenv("PMDI_LIGHT_IDS", str(thr))   # live clusters per step above which a chain is heavy
+    monkeypatch.setenv("PMDI_VERY_HEAVY", "2")       # the first two heavy chains of the launch order
+    rng = np.random.default_rng(21)
+    n, N, P, Cn, n1 = 260, 8, 512, 6, 60
+    z = rng.integers(0, 3, n)
+    x = rng.normal(size=(n, 6)) + 3.0 * (z[:, None] - 1)
+    sw = pkg.Sweeper([x], ["gaussian"], N, P, n_chains=Cn, seed=700)
+    assert sw.block_threads == 512
+    orc = [O.Oracle([x], ["gaussian"], N, P, seed=700 + c) for c in range(Cn)]
+    s = rng.integers(1, N + 1, size=(Cn, n, 1))
+    mixed = 0
+    for it in range(1, 6):
+        order = np.stack([rng.permutation(n) + 1 for _ in range(Cn)])
+        hyp = [random_hypers(rng, N, 1) for _ in range(Cn)]
+        r = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]))
+        for c in range(Cn):
+            o = orc[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1])
+            assert (r["s"][c] == o["s"]).all() and int(r["p_star"][c]) == o["p_star"], (it, c)
+            for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
+                assert r["stats"][c][key] == o["stats"][key], (it, c, key)
+        s = r["s"].copy()
+        ops = [st["n_operations"] / (n - n1 + 1) for st in r["stats"]]
+        if it < 5 and min(ops) <= thr < max(ops):    # the NEXT sweep runs light and heavy chains side by side
+            mixed += 1
+    assert mixed >= 1
+
+
 def test_pool_overflow_is_reported(pkg):
     rng = np.random.default_rng(4)
     x = rng.normal(size=(200, 4))                     # no structure: particles diverge, the pool grows
