@@ -177,6 +177,15 @@ int pmdi_cluster_stats(pmdi_cluster_batch *cb, double *out, int64_t *stride);
  * only n_chains*K*N integers cross PCIe per iteration.  Asynchronous on `stream`. */
 int pmdi_label_counts_device(pmdi_handle *h, const int32_t *s, int32_t *counts, void *stream);
 
+/* the co-clustering counts behind generate_psm (src/output_analysis/consensus_map.jl:50-56,
+ * psm[k][i, j] = sum(output[:, i] .== output[:, j]) / n_iter) for the block of rows [row_lo, row_hi):
+ *   counts[k][i - row_lo][j] = #{t : samples[t][k][i] == samples[t][k][j]},  full rows (the reference fills
+ * i > j only; the caller masks and divides by S).  samples: device-resident uint8 [S][K][n] (the pooled,
+ * all-gathered allocation samples of all chains); counts: device int32 [K][row_hi-row_lo][n].
+ * Stateless (no handle): `device` is the HIP device ordinal.  Asynchronous on `stream`. */
+int pmdi_psm_counts_device(int32_t device, const uint8_t *samples, int64_t S, int32_t K, int64_t n,
+                           int64_t row_lo, int64_t row_hi, int32_t *counts, void *stream);
+
 /* Debug: per-phase shader-clock totals of the last sweep (lane 0 of the chain's workgroup);
  * only when the environment variable PMDI_PHASE_TIMERS was set at pmdi_create. */
 int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);

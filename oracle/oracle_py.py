@@ -69,6 +69,8 @@ def lib():
     L.pmdi_oracle_cluster_logmarginal.argtypes = [vp, vp]
     L.pmdi_oracle_cluster_stats.restype = i64
     L.pmdi_oracle_cluster_stats.argtypes = [vp, vp]
+    L.pmdi_oracle_psm_counts.restype = None
+    L.pmdi_oracle_psm_counts.argtypes = [vp, i64, C.c_int32, i64, i64, i64, vp]
     L.pmdi_oracle_calc_ess.restype = dbl
     L.pmdi_oracle_calc_ess.argtypes = [vp, i64]
     L.pmdi_oracle_draw_partstar.argtypes = [vp, i64, dbl, dbl, vp]
@@ -234,6 +236,15 @@ class Cluster:
                 self.h = None
         except Exception:
             pass
+
+
+def psm_counts(samples, row_lo, row_hi):
+    """samples (S, K, n) uint8 -> (K, row_hi-row_lo, n) int32 co-clustering counts (consensus_map.jl:50-56)."""
+    smp = np.ascontiguousarray(samples, dtype=np.uint8)
+    S, K, n = smp.shape
+    out = np.zeros((K, row_hi - row_lo, n), dtype=np.int32)
+    lib().pmdi_oracle_psm_counts(_ptr(smp), S, K, n, row_lo, row_hi, _ptr(out))
+    return out
 
 
 def calc_ess(lw):

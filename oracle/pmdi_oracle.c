@@ -894,3 +894,20 @@ int64_t pmdi_oracle_cluster_stats(const pmdi_oracle_cluster *c, double *out)
     }
     return m;
 }
+
+/* output_analysis/consensus_map.jl:50-56 (generate_psm): the triple loop k, j, i with
+ * sum(output[:, i] .== output[:, j]); restated for a block of rows, full rows. */
+void pmdi_oracle_psm_counts(const uint8_t *samples, int64_t S, int32_t K, int64_t n,
+                            int64_t row_lo, int64_t row_hi, int32_t *counts)
+{
+    for (int32_t k = 0; k < K; ++k)
+        for (int64_t i = row_lo; i < row_hi; ++i)
+            for (int64_t j = 0; j < n; ++j) {
+                int32_t c = 0;
+                for (int64_t t = 0; t < S; ++t) {
+                    const uint8_t *row = samples + ((size_t)t * K + k) * n;
+                    c += (row[i] == row[j]) ? 1 : 0;
+                }
+                counts[((size_t)k * (row_hi - row_lo) + (i - row_lo)) * n + j] = c;
+            }
+}

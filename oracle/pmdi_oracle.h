@@ -111,6 +111,14 @@ void pmdi_oracle_draw_partstar(const double *logweight, int64_t P, double u01,
 void pmdi_oracle_phi_upweight(double *logweight, const int64_t *sstar_i,
                               int32_t K, const double *Phi, int64_t P);    /* misc.jl:50-59 */
 
+/* --- the co-clustering counts behind generate_psm -----------
+ * output_analysis/consensus_map.jl:50-56: psm[k][i, j] = sum(output[:, i] .== output[:, j]) / n_iter.
+ * samples: [S][K][n] labels (any byte values), counts: [K][row_hi-row_lo][n] with
+ * counts[k][i-row_lo][j] = #{t : samples[t][k][i] == samples[t][k][j]} (full rows; the reference
+ * fills i > j only and the caller masks). */
+void pmdi_oracle_psm_counts(const uint8_t *samples, int64_t S, int32_t K, int64_t n,
+                            int64_t row_lo, int64_t row_hi, int32_t *counts);
+
 /* --- counter-based RNG shared (as a specification) with the HIP path ---- */
 void pmdi_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double pmdi_oracle_uniform(uint64_t seed, uint32_t iter, uint32_t pos, uint32_t k,

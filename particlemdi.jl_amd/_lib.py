@@ -28,7 +28,7 @@ EXPORTS = [
     "pmdi_sweep_device", "pmdi_feature_select", "pmdi_export_state", "pmdi_clusters_new",
     "pmdi_clusters_free", "pmdi_cluster_add", "pmdi_calc_logprob", "pmdi_calc_logmarginal",
     "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L", "pmdi_phase_timers",
-    "pmdi_block_threads", "pmdi_lds_bytes", "pmdi_chain_costs", "pmdi_label_counts_device",
+    "pmdi_block_threads", "pmdi_lds_bytes", "pmdi_chain_costs", "pmdi_label_counts_device", "pmdi_psm_counts_device",
 ]
 
 
@@ -127,6 +127,8 @@ def lib():
     L.pmdi_block_threads.argtypes = [vp]
     L.pmdi_lds_bytes.restype = i64
     L.pmdi_lds_bytes.argtypes = [vp]
+    L.pmdi_psm_counts_device.restype = C.c_int
+    L.pmdi_psm_counts_device.argtypes = [C.c_int32, vp, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp, vp]
     L.pmdi_label_counts_device.restype = C.c_int
     L.pmdi_label_counts_device.argtypes = [vp, vp, vp, vp]
     L.pmdi_chain_costs.restype = C.c_int

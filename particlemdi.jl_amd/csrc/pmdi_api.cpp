@@ -496,6 +496,22 @@ int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const i
     return PMDI_OK;
 }
 
+int pmdi_psm_counts_device(int32_t device, const uint8_t *samples, int64_t S, int32_t K, int64_t n,
+                           int64_t row_lo, int64_t row_hi, int32_t *counts, void *stream)
+{
+    if (!samples || !counts) return fail(PMDI_E_ARG, "null argument");
+    if (S < 1 || K < 1 || n < 1 || row_lo < 0 || row_hi > n || row_lo > row_hi)
+        return fail(PMDI_E_ARG, "S=%lld K=%d n=%lld rows [%lld, %lld): out of range", (long long)S, K, (long long)n,
+                    (long long)row_lo, (long long)row_hi);
+    if (S > 2147483647LL) return fail(PMDI_E_ARG, "S=%lld samples overflow the int32 counts", (long long)S);
+    if ((n + 63) / 64 > 2147483647LL || (row_hi - row_lo + 63) / 64 > 65535 || K > 65535)
+        return fail(PMDI_E_ARG, "grid too large: split the rows into blocks of at most 4194240");
+    HIP_TRY(hipSetDevice(device));
+    hipError_t e = pmdi_launch_psm_counts(samples, S, K, n, row_lo, row_hi, counts, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "psm-count launch: %s", hipGetErrorString(e));
+    return PMDI_OK;
+}
+
 int pmdi_label_counts_device(pmdi_handle *h, const int32_t *s, int32_t *counts, void *stream)
 {
     if (!h || !s || !counts) return fail(PMDI_E_ARG, "null argument");

@@ -123,4 +123,6 @@ hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_
 hipError_t pmdi_launch_chain_order(const long long *cost, int *order, const long long *stats, unsigned char *group_flag,
                                    long long light_ops_max, int n_chains, hipStream_t stream);
 hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream);
+hipError_t pmdi_launch_psm_counts(const unsigned char *samples, long long S, int K, long long n, long long row_lo, long long row_hi,
+                                  int *counts, hipStream_t stream);
 hipError_t pmdi_launch_label_counts(const int *s, int *counts, int n_rows, long long n, int N, hipStream_t stream);

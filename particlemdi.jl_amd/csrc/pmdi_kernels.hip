@@ -250,6 +250,75 @@ __global__ void __launch_bounds__(256) label_count_kernel(const int *__restrict_
     for (int l = threadIdx.x; l < N; l += blockDim.x) counts[(size_t)row * N + l] = hist[l];
 }
 
+// generate_psm's co-clustering counts (consensus_map.jl:50-56).  One workgroup = a 64 x 64 tile of
+// (row i, column j) pairs of one dataset; 256 lanes, 4 x 4 pairs each.  The labels of 64 samples for the
+// tile's 64 rows and 64 columns are staged in LDS (sample-major, so a lane reads its 4 row labels and 4
+// column labels as one dword each); integer compares and adds only -- bit-exact by construction.
+#define PSM_TT 64
+__global__ void __launch_bounds__(256) psm_count_kernel(const unsigned char *__restrict__ samples, long long S, int K, long long n,
+                                                        long long row_lo, long long row_hi, int *__restrict__ counts)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char As[PSM_TT][64];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[PSM_TT][64];
+    const int k = blockIdx.z;
+    const long long i0 = row_lo + (long long)blockIdx.y * 64, j0 = (long long)blockIdx.x * 64;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    int acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0;
+    const int lc = tid & 63, lt = tid >> 6;                 // staging: column of the tile, sample row mod 4
+    for (long long t0 = 0; t0 < S; t0 += PSM_TT) {
+#pragma unroll 4
+        for (int tt = lt; tt < PSM_TT; tt += 4) {
+            const long long t = t0 + tt;
+            unsigned char av = 255, bv = 254;                // out of range: never equal to anything
+            if (t < S) {
+                const unsigned char *row = samples + ((size_t)t * K + k) * n;
+                if (i0 + lc < row_hi) av = row[i0 + lc];
+                if (j0 + lc < n) bv = row[j0 + lc];
+            }
+            As[tt][lc] = av; Bs[tt][lc] = bv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int tt = 0; tt < PSM_TT; ++tt) {
+            const unsigned a4 = *(const unsigned *)&As[tt][ty * 4];
+            const unsigned b4 = *(const unsigned *)&Bs[tt][tx * 4];
+            unsigned a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = (a4 >> (8 * r)) & 0xffu; b[r] = (b4 >> (8 * r)) & 0xffu; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] += (a[r] == b[c]) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    const long long rows = row_hi - row_lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long long i = i0 + ty * 4 + r;
+        if (i >= row_hi) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const long long j = j0 + tx * 4 + c;
+            if (j < n) counts[((size_t)k * rows + (i - row_lo)) * n + j] = acc[r][c];
+        }
+    }
+}
+
+hipError_t pmdi_launch_psm_counts(const unsigned char *samples, long long S, int K, long long n, long long row_lo, long long row_hi,
+                                  int *counts, hipStream_t stream)
+{
+    const long long rows = row_hi - row_lo;
+    if (rows <= 0 || n <= 0 || K <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)K);
+    hipLaunchKernelGGL(psm_count_kernel, grid, dim3(256), 0, stream, samples, S, K, n, row_lo, row_hi, counts);
+    return hipGetLastError();
+}
+
 hipError_t pmdi_launch_label_counts(const int *s, int *counts, int n_rows, long long n, int N, hipStream_t stream)
 {
     hipLaunchKernelGGL(label_count_kernel, dim3(n_rows), dim3(256), 0, stream, s, counts, n, N);

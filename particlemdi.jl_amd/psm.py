@@ -22,6 +22,24 @@ def allgather_samples(samples):
     return out
 
 
+def psm_counts_device(samples, row_lo, row_hi):
+    """Co-clustering counts (consensus_map.jl:50-56) on the MI355X: samples is a CUDA uint8 tensor
+    (S, K, n); returns an int32 CUDA tensor (K, row_hi-row_lo, n) with
+    counts[k, i-row_lo, j] = #{t : samples[t, k, i] == samples[t, k, j]} (libpmdi_hip.so, pmdi_psm_counts_device)."""
+    import ctypes as C
+    import torch
+    from ._lib import _check, lib
+    if not samples.is_cuda or samples.dtype != torch.uint8:
+        raise ValueError("psm_counts_device needs a CUDA uint8 tensor (S, K, n)")
+    smp = samples.contiguous()
+    S, K, n = smp.shape
+    out = torch.empty((K, row_hi - row_lo, n), dtype=torch.int32, device=smp.device)
+    st = torch.cuda.current_stream(smp.device)
+    _check(lib().pmdi_psm_counts_device(smp.device.index or 0, C.c_void_p(smp.data_ptr()), S, K, n, int(row_lo), int(row_hi),
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(st.cuda_stream)))
+    return out
+
+
 def psm_rows(samples, row_lo, row_hi):
     """Rows [row_lo, row_hi) of the K (+1) posterior-similarity matrices from pooled samples
     (S, K, n); lower triangle as the reference fills it, identity elsewhere.  Works on torch
@@ -38,15 +56,21 @@ def psm_rows(samples, row_lo, row_hi):
     cols = torch.arange(n, device=samples.device)
     lower = (rows[:, None] > cols[None, :])
     eye = (rows[:, None] == cols[None, :]).to(torch.float64)
+    S_t = torch.full((), float(S), dtype=torch.float64, device=samples.device)
+    K_t = torch.full((), float(K), dtype=torch.float64, device=samples.device)
+    dev_counts = psm_counts_device(samples, row_lo, row_hi) if samples.is_cuda else None   # the HIP kernel
     for k in range(K):
-        acc = torch.zeros((row_hi - row_lo, n), dtype=torch.float64, device=samples.device)
-        for t in range(S):
-            lab = samples[t, k]
-            acc += (lab[row_lo:row_hi, None] == lab[None, :]).to(torch.float64)
-        out[k] = (acc / S) * lower + eye
+        if dev_counts is not None:
+            acc = dev_counts[k].to(torch.float64)
+        else:       # host tensors (the gloo rehearsal of the exchange step): plain torch
+            acc = torch.zeros((row_hi - row_lo, n), dtype=torch.float64, device=samples.device)
+            for t in range(S):
+                lab = samples[t, k]
+                acc += (lab[row_lo:row_hi, None] == lab[None, :]).to(torch.float64)
+        out[k] = torch.div(acc, S_t) * lower + eye      # tensor divisor: an IEEE division on every backend
     if K > 1:
         out[K] = eye
         for k in range(K):
-            out[K] += out[k] / K
+            out[K] += torch.div(out[k], K_t)
         out[K] = out[K] * (1.0 - eye) + eye       # diagind .= 1.0
     return out.numpy() if is_np else out

@@ -119,3 +119,19 @@ def test_label_counts_on_device(pkg):
     got = sw.label_counts(s)
     want = np.stack([[np.bincount(s[c, k] - 1, minlength=N) for k in range(K)] for c in range(Cn)])
     assert got.shape == (Cn, K, N) and (got == want).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,K,n,lo,hi", [(1, 1, 1, 0, 1), (37, 2, 53, 0, 53), (130, 3, 257, 64, 201), (65, 1, 1000, 500, 1000)])
+def test_psm_counts_on_device(pkg, O, S, K, n, lo, hi):
+    # co-clustering counts of generate_psm (consensus_map.jl:50-56), integer-exact
+    import torch
+    from particlemdi_jl_amd import psm
+    rng = np.random.default_rng(S * 7 + n)
+    smp = rng.integers(0, 12, size=(S, K, n)).astype(np.uint8)
+    got = psm.psm_counts_device(torch.from_numpy(smp).cuda(), lo, hi).cpu().numpy()
+    assert (got == O.psm_counts(smp, lo, hi)).all()
+    # and the posterior-similarity rows built from it equal the host mirror's
+    rows_dev = psm.psm_rows(torch.from_numpy(smp).cuda(), lo, hi).cpu().numpy()
+    rows_host = psm.psm_rows(smp, lo, hi)
+    assert (rows_dev == rows_host).all()

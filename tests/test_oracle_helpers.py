@@ -80,3 +80,18 @@ def test_phi_upweight(O):
     for i, (a, b) in enumerate(pairs):
         want += (ss[:, a] == ss[:, b]) * np.log(1 + Phi[i])
     assert np.allclose(got, want, rtol=0, atol=1e-15)
+
+
+def test_psm_counts_known_answers(O):
+    # generate_psm's inner expression (consensus_map.jl:53): sum(output[:, i] .== output[:, j])
+    rng = np.random.default_rng(8)
+    S, K, n = 37, 2, 53
+    smp = rng.integers(1, 6, size=(S, K, n)).astype(np.uint8)
+    smp[:, 0, 7] = smp[:, 0, 3]                       # two observations always together
+    smp[:, 1, 9] = 200                                # a label nobody else uses
+    got = O.psm_counts(smp, 0, n)
+    want = (smp[:, :, :, None] == smp[:, :, None, :]).sum(axis=0).astype(np.int32)
+    assert (got == want).all()
+    assert (got[:, np.arange(n), np.arange(n)] == S).all() and got[0, 7, 3] == S and (np.delete(got[1, 9], 9) == 0).all()
+    blk = O.psm_counts(smp, 11, 30)                   # a block of rows == the same rows of the full matrix
+    assert (blk == want[:, 11:30, :]).all()
