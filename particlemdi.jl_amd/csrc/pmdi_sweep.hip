@@ -459,6 +459,31 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
 
 }
 
+// The fallback step's list of distinct chosen clusters, (src id, updated id, new n) per entry.  The
+// fast path's tables are idle during a fallback step, so the list lives in two LDS regions of theirs
+// (need .. dl: 8 * PMDI_ITEM_CAP + 3 * PMDI_DL_LDS ints, contiguous; fl_p .. fl_tgt: 4 * PMDI_HT_SIZE ints)
+// and only what exceeds them (> 1 492 clusters) goes to the arena.  ktab_minp lies inside the first
+// region: the fallback step re-arms it (INF) before it returns.
+struct DList {
+    lint a, b;
+    gint g;
+    int P;
+    static constexpr int CA = (8 * PMDI_ITEM_CAP + 3 * PMDI_DL_LDS) / 3, CB = (4 * PMDI_HT_SIZE) / 3;
+    __device__ __forceinline__ void set(int j, int src, int dst, int nnew) const
+    {
+        if (j < CA) { a[j] = src; a[CA + j] = dst; a[2 * CA + j] = nnew; }
+        else if (j < CA + CB) { const int e = j - CA; b[e] = src; b[CB + e] = dst; b[2 * CB + e] = nnew; }
+        else { g[j] = src; g[P + j] = dst; g[2 * P + j] = nnew; }
+    }
+    __device__ __forceinline__ int src(int j) const { return j < CA ? a[j] : (j < CA + CB ? b[j - CA] : g[j]); }
+    __device__ __forceinline__ void get(int j, int &src_, int &dst, int &nnew) const
+    {
+        if (j < CA) { src_ = a[j]; dst = a[CA + j]; nnew = a[2 * CA + j]; }
+        else if (j < CA + CB) { const int e = j - CA; src_ = b[e]; dst = b[CB + e]; nnew = b[2 * CB + e]; }
+        else { src_ = g[j]; dst = g[P + j]; nnew = g[2 * P + j]; }
+    }
+};
+
 // deepcopy + cluster_add! of every distinct chosen cluster (src/pmdi.jl:297,:300): lanes =
 // (cluster, feature).  item(j, src, dst, nnew) names the j-th chosen cluster.  The clusters of a
 // chain that still carries hundreds of private copies are spread over megabytes of pool, so
@@ -525,6 +550,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
     const int items = ncls * N;
     const Dual<double> cdfp = dual(small, sh.cdf, s.cdf);
+    const DList dl{sh.need, sh.fl_p, s.dl, P};
     int nd = 0, nclone = 0, new_ncls = 0, failed = 0;
     (void)items;
     if (converted) {
@@ -638,12 +664,8 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                             const int nnew = s.cn[c] + 1;
                             if (nc) { s.counts[c] -= ncp; s.counts[tgt] = ncp; }   // (:293-294)
                             s.cn[tgt] = nnew;
-                            if (rc < PMDI_DL_LDS) {
-                                sh.dl[rc] = c; sh.dl[PMDI_DL_LDS + rc] = tgt; sh.dl[2 * PMDI_DL_LDS + rc] = nnew;
-                                sh.dl_slot[rc] = slot;
-                            } else {
-                                s.dl[rc] = c; s.dl[P + rc] = tgt; s.dl[2 * P + rc] = nnew;
-                            }
+                            dl.set(rc, c, tgt, nnew);
+                            if (rc < PMDI_DL_LDS) sh.dl_slot[rc] = slot;
                             if (gcensus) s.ncop[c] = tgt; else sh.h2.a[slot] = tgt;   // chosen id -> updated id
                         }
                     }
@@ -696,7 +718,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                     }
                     if (gcensus) {
                         for (int j = tid; j < nd; j += T) {
-                            const int c = j < PMDI_DL_LDS ? sh.dl[j] : s.dl[j];
+                            const int c = dl.src(j);
                             s.ncop[c] = 0; s.firstc[c] = PMDI_INF_I;
                         }
                     } else if (nd <= PMDI_DL_LDS) {
@@ -706,14 +728,14 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                     }
                     PHS(13);
                     stats_update_all<T, (T >= 512 && WPS <= 2) ? 8 : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
-                        if (j < PMDI_DL_LDS) { src = sh.dl[j]; dst = sh.dl[PMDI_DL_LDS + j]; nnew = sh.dl[2 * PMDI_DL_LDS + j]; }
-                        else { src = s.dl[j]; dst = s.dl[P + j]; nnew = s.dl[2 * P + j]; }
+                        dl.get(j, src, dst, nnew);
                     });
                     new_ncls = (int)ccarry;
                     __syncthreads();
                     for (int r = tid; r < new_ncls; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
                 }
     }
+    for (int e = tid; e < PMDI_ITEM_CAP; e += T) sh.ktab_minp[e] = PMDI_INF_I;     // it lies inside the list's LDS region
     if (tid == 0) {
         sh.misc[M_NCLONE] = nclone; sh.misc[M_NCLS] = new_ncls;
         sh.khint[k] = (gcensus && nd > PMDI_HT_SIZE / 4) ? 1 : 0;   // stay on the global census while it is needed
@@ -724,17 +746,11 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
 
 // draw_partstar (src/misc.jl:27-47), gather and compact renumbering (src/pmdi.jl:318-340)
 template <int T>
-__device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ ap, long long pos, double mx,
-                                                  long long &ph_last, int &ph_cur)
+__device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ ap, long long pos, double mx)
 {
+    // (no phase-timer references in here: a __noinline__ function that takes the address of the step
+    // loop's timer variables pins them in memory and costs the 128-register build ~50 more spill slots)
     PMDI_PREAMBLE;
-#define PHR(i_)                                                                 \
-    do {                                                                        \
-        if (a.phase && tid == 0) {                                              \
-            const long long t_ = clock64();                                     \
-            sh.ph[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_);         \
-        }                                                                       \
-    } while (0)
             // draw_partstar (src/misc.jl:27-47)
             const double u01 = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
             const double usl = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
@@ -985,8 +1001,6 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 if (tid == 0) { sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1; }
                 __syncthreads();
             }
-    PHR(10);
-#undef PHR
 }
 
 // particle pick (src/pmdi.jl:345-350), s = sstar[p_star,:,:] (:373), counters
@@ -1632,7 +1646,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         if (resample) {
             PH(10);
             ++st_nres;
-            sweep_resample<T>(ap, pos, mx, ph_last, ph_cur);
+            sweep_resample<T>(ap, pos, mx);
             lw_uniform = true;
         }
 

@@ -1,0 +1,38 @@
+"""Register-spill budget of the sweep kernel builds (no GPU needed: hipcc cross-compiles).
+
+The 128-register build of the heavy group is sensitive to innocent-looking source changes: taking the
+address of a step-loop variable in an out-of-line device function cost ~50 more spill slots and made
+heavy chains 20 % slower (profiles/README.md).  This test keeps the spill counts from creeping."""
+import os
+import re
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "particlemdi.jl_amd", "csrc", "pmdi_sweep.hip")
+BUDGET = {            # (T, WPS, K1) -> max VGPR spill slots; measured 158 / 19 / 8 when this was written
+    "ILi512ELi4ELb1": 175,
+    "ILi512ELi2ELb1": 40,
+    "ILi256ELi2ELb1": 25,
+}
+
+
+def test_spill_budget_of_the_sweep_kernel_builds():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                            "--cuda-device-only", "-c", SRC, "-o", os.path.join(tmp, "x.o"),
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    spills, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: \S*pmdi_sweep_kernel(\w+?)EEEvPK9SweepArgs", line)
+        if m:
+            cur = m.group(1)
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and cur:
+            spills[cur] = int(m.group(1))
+            cur = None
+    for variant, limit in BUDGET.items():
+        assert variant in spills, (variant, sorted(spills))
+        assert spills[variant] <= limit, f"pmdi_sweep_kernel<{variant}> spills {spills[variant]} VGPRs (budget {limit})"
