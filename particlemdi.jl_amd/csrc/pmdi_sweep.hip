@@ -111,7 +111,7 @@ __device__ __forceinline__ void lds_barrier()
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
         need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v,
-        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, lab, misc, ph,
+        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, lab, misc, ph, stat,
         fl, news, total;
 };
 
@@ -125,6 +125,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.red = take(48 * 8);
     c.misc = take(16 * 4);
     c.ph = take(16 * 8);
+    c.stat = take(8 * 8);
     c.kmaxid = take(PMDI_KMAX_I * 4);
     c.kncls = take(PMDI_KMAX_I * 4);
     c.kcur = take(PMDI_KMAX_I * 4);
@@ -187,7 +188,7 @@ struct Sh {
     ldbl leaf_tot, leaf_carry;
     lu8 leaf_prog;
     lint kmaxid, kncls, kcur, knflag, khint, lab, misc;
-    li64 ph;
+    li64 ph, stat;   // phase timers; the sweep's counters (n_operations, ...), kept by lane 0
     lu8 fl, news;
 };
 
@@ -315,7 +316,7 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
         sh.leaf_i1 = (lint)(smem + c.leaf_i1); sh.leaf_n = (lint)(smem + c.leaf_n);
         sh.leaf_tot = (ldbl)(smem + c.leaf_tot); sh.leaf_carry = (ldbl)(smem + c.leaf_carry); sh.leaf_prog = (lu8)(smem + c.leaf_prog);
         sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag); sh.khint = (lint)(smem + c.khint);
-        sh.lab = (lint)(smem + c.lab); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph);
+        sh.lab = (lint)(smem + c.lab); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph); sh.stat = (li64)(smem + c.stat);
         sh.fl = (lu8)(smem + c.fl); sh.news = (lu8)(smem + c.news);
 }
 
@@ -1005,9 +1006,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
 
 // particle pick (src/pmdi.jl:345-350), s = sstar[p_star,:,:] (:373), counters
 template <int T>
-__device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap, long long st_nops, long long st_nres,
-                                         long long st_nclones, long long st_maxid, long long st_sumcls,
-                                         long long st_fast, long long st_conv, long long st_slow)
+__device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
 {
     PMDI_PREAMBLE;
     // ---- particle pick (src/pmdi.jl:345-350) + s = sstar[p_star,:,:] (:373) ----
@@ -1054,9 +1053,9 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap, lo
         if (tid == 0) {
             a.pstar[chain] = pstar;
             long long *st = a.stats + (size_t)chain * 8;
-            st[ST_NOPS] = st_nops; st[ST_NRESAMPLE] = st_nres; st[ST_NCLONES] = st_nclones;
-            st[ST_MAXID] = st_maxid; st[ST_SUMCLASSES] = st_sumcls;
-            st[5] = st_fast; st[6] = st_conv; st[7] = st_slow;
+            st[ST_NOPS] = sh.stat[0]; st[ST_NRESAMPLE] = sh.stat[1]; st[ST_NCLONES] = sh.stat[2];
+            st[ST_MAXID] = sh.stat[3]; st[ST_SUMCLASSES] = sh.stat[4];
+            st[5] = sh.stat[5]; st[6] = sh.stat[6]; st[7] = sh.stat[7];
             a.err[chain] = 0;
         }
     }
@@ -1075,8 +1074,8 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || (int)blockIdx.x < a.rank_lo || (int)blockIdx.x >= a.rank_hi)) return;
 
     const long long t_start = clock64();
-    long long st_nops = 0, st_nres = 0, st_nclones = 0, st_maxid = 0, st_sumcls = 0;
-    long long st_fast = 0, st_conv = 0, st_slow = 0;
+    if (tid < 8) sh.stat[tid] = 0;    // the sweep's counters live in LDS, kept by lane 0: eight 64-bit values less across
+                                      // the step loop (the 128-register build: 158 -> 124 spill slots)
     long long ph_last = 0;
     int ph_cur = 0;
 #define PH(i_)                                                                  \
@@ -1597,12 +1596,14 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 new_ncls = sh.misc[M_NCLS];
             }
             }
-            if (fast) ++st_fast; else if (converted) ++st_conv; else ++st_slow;
-            st_nops += maxid;                     // src/__pmdi.jl:187
-            st_sumcls += ncls;
-            st_nclones += nclone;
-            if (maxid + nclone > st_maxid) st_maxid = maxid + nclone;
-            if (tid == 0) { sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = new_ncls; }
+            if (tid == 0) {
+                sh.stat[fast ? 5 : (converted ? 6 : 7)] += 1;
+                sh.stat[0] += maxid;                  // src/__pmdi.jl:187
+                sh.stat[4] += ncls;
+                sh.stat[2] += nclone;
+                if (maxid + nclone > sh.stat[3]) sh.stat[3] = maxid + nclone;
+                sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = new_ncls;
+            }
             __syncthreads();
 #undef FRESH_LANE_IDS
             }
@@ -1645,7 +1646,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 
         if (resample) {
             PH(10);
-            ++st_nres;
+            if (tid == 0) sh.stat[1] += 1;
             sweep_resample<T>(ap, pos, mx);
             lw_uniform = true;
         }
@@ -1664,7 +1665,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     }
 
     PH(11);
-    sweep_final<T>(ap, st_nops, st_nres, st_nclones, st_maxid, st_sumcls, st_fast, st_conv, st_slow);
+    sweep_final<T>(ap);
     PH(12);
     if (tid == 0) a.cost[chain] = clock64() - t_start;
     if (a.phase && tid == 0) {
