@@ -70,7 +70,7 @@ typedef struct {
     int32_t q1_mode;       /* 0 reference: new_id zeroed per iteration (src/pmdi.jl:167); 1: per step */
     int32_t q2_mode;       /* 0 pmdi(): history not permuted on resample (src/pmdi.jl:321-324); 1 __pmdi() (src/__pmdi.jl:285) */
     int64_t pool_cap;      /* cluster pool ids per dataset; 0 = N*P+1 (src/pmdi.jl:140) */
-    int32_t block_threads; /* 0 = choose; else 256/512/1024 */
+    int32_t block_threads; /* 0 = choose (and split the chains of a sweep into concurrent launches by weight); else 128/256/512/1024 */
     int32_t reserved;
 } pmdi_config;
 

@@ -63,7 +63,7 @@ def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, b
     return g
 
 
-@pytest.mark.parametrize("P,iters,block", [(2, 2, 0), (64, 3, 0), (1024, 3, 0), (1024, 2, 256), (1024, 2, 1024), (300, 2, 0)])
+@pytest.mark.parametrize("P,iters,block", [(2, 2, 0), (64, 3, 0), (1024, 3, 0), (1024, 2, 128), (1024, 2, 256), (1024, 2, 512), (1024, 2, 1024), (300, 2, 0)])
 def test_T5_problem(pkg, O, P, iters, block):
     # the reference's integration problem: test/runtests.jl:136-162
     rng = np.random.default_rng(0)
