@@ -182,9 +182,12 @@ int pmdi_label_counts_device(pmdi_handle *h, const int32_t *s, int32_t *counts, 
  *   counts[k][i - row_lo][j] = #{t : samples[t][k][i] == samples[t][k][j]},  full rows (the reference fills
  * i > j only; the caller masks and divides by S).  samples: device-resident uint8 [S][K][n] (the pooled,
  * all-gathered allocation samples of all chains); counts: device int32 [K][row_hi-row_lo][n].
+ * n_labels: every label is < n_labels (the model's N; 0 = unknown).  With 1 <= n_labels <= 64 the counts are
+ * computed as a one-hot int8 GEMM on the matrix cores, otherwise by byte compares; both are exact, but a label
+ * >= a non-zero n_labels is a caller error (its matches are not counted).
  * Stateless (no handle): `device` is the HIP device ordinal.  Asynchronous on `stream`. */
 int pmdi_psm_counts_device(int32_t device, const uint8_t *samples, int64_t S, int32_t K, int64_t n,
-                           int64_t row_lo, int64_t row_hi, int32_t *counts, void *stream);
+                           int64_t row_lo, int64_t row_hi, int32_t n_labels, int32_t *counts, void *stream);
 
 /* Debug: per-phase shader-clock totals of the last sweep (lane 0 of the chain's workgroup);
  * only when the environment variable PMDI_PHASE_TIMERS was set at pmdi_create. */

@@ -128,7 +128,7 @@ def lib():
     L.pmdi_lds_bytes.restype = i64
     L.pmdi_lds_bytes.argtypes = [vp]
     L.pmdi_psm_counts_device.restype = C.c_int
-    L.pmdi_psm_counts_device.argtypes = [C.c_int32, vp, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, vp, vp]
+    L.pmdi_psm_counts_device.argtypes = [C.c_int32, vp, C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, vp, vp]
     L.pmdi_label_counts_device.restype = C.c_int
     L.pmdi_label_counts_device.argtypes = [vp, vp, vp, vp]
     L.pmdi_chain_costs.restype = C.c_int

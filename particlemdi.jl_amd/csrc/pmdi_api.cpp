@@ -497,7 +497,7 @@ int pmdi_sweep_device(pmdi_handle *h, int64_t iter, const int32_t *s_in, const i
 }
 
 int pmdi_psm_counts_device(int32_t device, const uint8_t *samples, int64_t S, int32_t K, int64_t n,
-                           int64_t row_lo, int64_t row_hi, int32_t *counts, void *stream)
+                           int64_t row_lo, int64_t row_hi, int32_t n_labels, int32_t *counts, void *stream)
 {
     if (!samples || !counts) return fail(PMDI_E_ARG, "null argument");
     if (S < 1 || K < 1 || n < 1 || row_lo < 0 || row_hi > n || row_lo > row_hi)
@@ -507,7 +507,11 @@ int pmdi_psm_counts_device(int32_t device, const uint8_t *samples, int64_t S, in
     if ((n + 63) / 64 > 2147483647LL || (row_hi - row_lo + 63) / 64 > 65535 || K > 65535)
         return fail(PMDI_E_ARG, "grid too large: split the rows into blocks of at most 4194240");
     HIP_TRY(hipSetDevice(device));
-    hipError_t e = pmdi_launch_psm_counts(samples, S, K, n, row_lo, row_hi, counts, (hipStream_t)stream);
+    if (n_labels < 0 || n_labels > 256) return fail(PMDI_E_ARG, "n_labels=%d outside 0..256", n_labels);
+    // labels known to be < 64: one-hot int8 GEMM on the matrix cores; otherwise byte compares on the vector ALUs
+    const bool mfma = n_labels >= 1 && n_labels <= 64 && (row_hi - row_lo + 127) / 128 <= 65535;
+    hipError_t e = mfma ? pmdi_launch_psm_counts_mfma(samples, S, K, n, row_lo, row_hi, n_labels, counts, (hipStream_t)stream)
+                        : pmdi_launch_psm_counts(samples, S, K, n, row_lo, row_hi, counts, (hipStream_t)stream);
     if (e != hipSuccess) return fail(PMDI_E_DEVICE, "psm-count launch: %s", hipGetErrorString(e));
     return PMDI_OK;
 }

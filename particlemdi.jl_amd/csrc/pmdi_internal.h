@@ -125,4 +125,6 @@ hipError_t pmdi_launch_chain_order(const long long *cost, int *order, const long
 hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream);
 hipError_t pmdi_launch_psm_counts(const unsigned char *samples, long long S, int K, long long n, long long row_lo, long long row_hi,
                                   int *counts, hipStream_t stream);
+hipError_t pmdi_launch_psm_counts_mfma(const unsigned char *samples, long long S, int K, long long n, long long row_lo, long long row_hi,
+                                       int n_labels, int *counts, hipStream_t stream);
 hipError_t pmdi_launch_label_counts(const int *s, int *counts, int n_rows, long long n, int N, hipStream_t stream);

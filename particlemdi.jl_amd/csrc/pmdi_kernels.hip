@@ -309,6 +309,101 @@ __global__ void __launch_bounds__(256) psm_count_kernel(const unsigned char *__r
     }
 }
 
+// The same counts on the matrix cores, for labels known to be < 32 * NKB: with one-hot rows
+// A[i][(t, l)] = [samples[t][i] == l] the counts are A * A^T, an int8 GEMM whose K dimension is
+// (sample, label).  One v_mfma_i32_32x32x32_i8 covers one sample x 32 labels for a 32 x 32 tile of pairs.
+// Workgroup = 4 waves = a 128 x 128 tile; each wave a 64 x 64 quadrant (4 accumulator tiles).  The one-hot
+// fragments are built in registers from the staged label bytes: lane (r = l & 31, h = l >> 5) holds 16 of
+// the 32 k-values of row r; which 16 does not matter as long as A and B use the same rule, because the
+// sum over k is permutation-invariant and the hardware pairs A's and B's k by the same (h, byte) position.
+// C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cdna_hip_programming.md).
+typedef int psm_v4i __attribute__((ext_vector_type(4)));
+typedef int psm_v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ psm_v4i psm_onehot(int label, int kb, int h)
+{
+    const unsigned x = (unsigned)(label - 32 * kb - 16 * h);      // byte position among this lane's 16 k-values
+    const unsigned bit = (x < 16u) ? (1u << ((x & 3u) * 8u)) : 0u;
+    const unsigned dw = x >> 2;
+    psm_v4i f;
+    f.x = (dw == 0u) ? (int)bit : 0; f.y = (dw == 1u) ? (int)bit : 0; f.z = (dw == 2u) ? (int)bit : 0; f.w = (dw == 3u) ? (int)bit : 0;
+    return f;
+}
+
+#define PSM_MT 32       // samples staged per round
+template <int NKB>
+__global__ void __launch_bounds__(256) psm_count_mfma_kernel(const unsigned char *__restrict__ samples, long long S, int K, long long n,
+                                                             long long row_lo, long long row_hi, int *__restrict__ counts)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char As[PSM_MT][128];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[PSM_MT][128];
+    const int k = blockIdx.z;
+    const long long i0 = row_lo + (long long)blockIdx.y * 128, j0 = (long long)blockIdx.x * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wy = wave >> 1, wx = wave & 1;                   // this wave's 64 x 64 quadrant
+    const int r = lane & 31, h = lane >> 5;
+    psm_v16i acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+    const int lc = tid & 127, lt = tid >> 7;                   // staging: column of the tile, sample row mod 2
+    for (long long t0 = 0; t0 < S; t0 += PSM_MT) {
+#pragma unroll 4
+        for (int tt = lt; tt < PSM_MT; tt += 2) {
+            const long long t = t0 + tt;
+            unsigned char av = 255, bv = 254;                  // out of range: outside every 32-label block used
+            if (t < S) {
+                const unsigned char *row = samples + ((size_t)t * K + k) * n;
+                if (i0 + lc < row_hi) av = row[i0 + lc];
+                if (j0 + lc < n) bv = row[j0 + lc];
+            }
+            As[tt][lc] = av; Bs[tt][lc] = bv;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int tt = 0; tt < PSM_MT; ++tt) {
+            const int a0 = As[tt][wy * 64 + r], a1 = As[tt][wy * 64 + 32 + r];
+            const int b0 = Bs[tt][wx * 64 + r], b1 = Bs[tt][wx * 64 + 32 + r];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const psm_v4i fa0 = psm_onehot(a0, kb, h), fa1 = psm_onehot(a1, kb, h);
+                const psm_v4i fb0 = psm_onehot(b0, kb, h), fb1 = psm_onehot(b1, kb, h);
+                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0, fb0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0, fb1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1, fb0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1, fb1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const long long rows = row_hi - row_lo;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long i = i0 + wy * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const long long j = j0 + wx * 64 + b * 32 + r;
+                if (i < row_hi && j < n) counts[((size_t)k * rows + (i - row_lo)) * n + j] = acc[a][b][e];
+            }
+}
+
+hipError_t pmdi_launch_psm_counts_mfma(const unsigned char *samples, long long S, int K, long long n, long long row_lo, long long row_hi,
+                                       int n_labels, int *counts, hipStream_t stream)
+{
+    const long long rows = row_hi - row_lo;
+    if (rows <= 0 || n <= 0 || K <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n + 127) / 128), (unsigned)((rows + 127) / 128), (unsigned)K);
+    if (n_labels <= 32) hipLaunchKernelGGL(psm_count_mfma_kernel<1>, grid, dim3(256), 0, stream, samples, S, K, n, row_lo, row_hi, counts);
+    else if (n_labels <= 64) hipLaunchKernelGGL(psm_count_mfma_kernel<2>, grid, dim3(256), 0, stream, samples, S, K, n, row_lo, row_hi, counts);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t pmdi_launch_psm_counts(const unsigned char *samples, long long S, int K, long long n, long long row_lo, long long row_hi,
                                   int *counts, hipStream_t stream)
 {

@@ -22,10 +22,11 @@ def allgather_samples(samples):
     return out
 
 
-def psm_counts_device(samples, row_lo, row_hi):
+def psm_counts_device(samples, row_lo, row_hi, n_labels=0):
     """Co-clustering counts (consensus_map.jl:50-56) on the MI355X: samples is a CUDA uint8 tensor
     (S, K, n); returns an int32 CUDA tensor (K, row_hi-row_lo, n) with
-    counts[k, i-row_lo, j] = #{t : samples[t, k, i] == samples[t, k, j]} (libpmdi_hip.so, pmdi_psm_counts_device)."""
+    counts[k, i-row_lo, j] = #{t : samples[t, k, i] == samples[t, k, j]} (libpmdi_hip.so, pmdi_psm_counts_device).
+    n_labels: every label is < n_labels (the model's N); 1..64 selects the matrix-core kernel, 0 = unknown."""
     import ctypes as C
     import torch
     from ._lib import _check, lib
@@ -36,11 +37,11 @@ def psm_counts_device(samples, row_lo, row_hi):
     out = torch.empty((K, row_hi - row_lo, n), dtype=torch.int32, device=smp.device)
     st = torch.cuda.current_stream(smp.device)
     _check(lib().pmdi_psm_counts_device(smp.device.index or 0, C.c_void_p(smp.data_ptr()), S, K, n, int(row_lo), int(row_hi),
-                                        C.c_void_p(out.data_ptr()), C.c_void_p(st.cuda_stream)))
+                                        int(n_labels), C.c_void_p(out.data_ptr()), C.c_void_p(st.cuda_stream)))
     return out
 
 
-def psm_rows(samples, row_lo, row_hi):
+def psm_rows(samples, row_lo, row_hi, n_labels=0):
     """Rows [row_lo, row_hi) of the K (+1) posterior-similarity matrices from pooled samples
     (S, K, n); lower triangle as the reference fills it, identity elsewhere.  Works on torch
     tensors (any device) or numpy arrays.  The rows of a matrix are independent, so ranks
@@ -58,7 +59,7 @@ def psm_rows(samples, row_lo, row_hi):
     eye = (rows[:, None] == cols[None, :]).to(torch.float64)
     S_t = torch.full((), float(S), dtype=torch.float64, device=samples.device)
     K_t = torch.full((), float(K), dtype=torch.float64, device=samples.device)
-    dev_counts = psm_counts_device(samples, row_lo, row_hi) if samples.is_cuda else None   # the HIP kernel
+    dev_counts = psm_counts_device(samples, row_lo, row_hi, n_labels) if samples.is_cuda else None   # the HIP kernels
     for k in range(K):
         if dev_counts is not None:
             acc = dev_counts[k].to(torch.float64)
