@@ -212,11 +212,13 @@ def main():
                                  "steps_fast_frac": float(stats[:, 5].sum()) / float(stats[:, 5:8].sum())},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "traffic_frac": (traffic / (kernel_ms * 1e-3) / HBM_PEAK) if traffic else None,
                          "note": "achieved = dense-model algorithmic bytes (SURVEY 8d: 19392 B per obs*particle) / "
                                  "kernel time. The kernel de-duplicates clusters and particle classes like the "
                                  "reference does, so it moves far fewer bytes than the dense model and frac > 1 "
-                                 "is expected; `traffic` is the PMC-measured HBM bytes per launch. The kernel is "
-                                 "bound by dependent latency / instruction issue, not by HBM (DESIGN.md section 6)."},
+                                 "is expected; `traffic` is the PMC-measured HBM bytes per sweep and `traffic_frac` that traffic / "
+                                 "sweep time / peak. A sweep ends with its slowest chain; converged chains are bound by dependent "
+                                 "latency, chains with many private clusters by HBM round trips (DESIGN.md section 6)."},
         }
     if dist is not None:
         dist.destroy_process_group()
