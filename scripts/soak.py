@@ -1,0 +1,79 @@
+"""Randomised parity soak: the HIP sweep (through the C ABI) against the oracle on many small random
+configurations -- data types, N, P, K, chains, quirk switch, flags, workgroup widths, launch-split thresholds.
+Usage: python scripts/soak.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as G
+pkg = G.load_package(); O = G.load_oracle()
+
+
+def run(budget, seed, max_cases=10**9, verbose=True):
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + budget
+    ncase = 0
+    saved = {k: os.environ.get(k) for k in ("PMDI_LIGHT_IDS", "PMDI_VERY_HEAVY")}
+    try:
+        while time.time() < t_end and ncase < max_cases:
+            ncase += _one_case(rng)
+            if verbose and ncase % 20 == 0:
+                print(f"{ncase} configurations equal", flush=True)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return ncase
+
+
+def _one_case(rng):
+    K = int(rng.integers(1, 4)); n = int(rng.integers(30, 220)); N = int(rng.integers(2, 21))
+    P = int(rng.choice([2, 8, 33, 64, 200, 256, 512, 1024])); Cn = int(rng.integers(1, 5)); q1 = int(rng.integers(0, 2))
+    block = int(rng.choice([0, 0, 0, 128, 256, 512, 1024])); n1 = int(rng.integers(1, n + 1)); iters = int(rng.integers(1, 5))
+    os.environ["PMDI_LIGHT_IDS"] = str(int(rng.choice([2, 10, 40, 400])))
+    os.environ["PMDI_VERY_HEAVY"] = str(int(rng.choice([0, 1, 2, 128])))
+    z = rng.integers(0, 3, n); sep = float(rng.choice([0.0, 1.0, 3.0]))
+    data, kinds = [], []
+    for k in range(K):
+        kind = str(rng.choice(["gaussian", "categorical", "negbinom"])); D = int(rng.integers(1, 9))
+        if kind == "gaussian": x = rng.normal(size=(n, D)) + sep * (z[:, None] - 1)
+        elif kind == "categorical": x = 1 + rng.integers(0, 2, (n, D)) + (z[:, None] == 2) * rng.integers(0, 3, (n, D))
+        else: x = rng.geometric(0.2 + 0.2 * z[:, None], size=(n, D)) - 1
+        data.append(x); kinds.append(kind)
+    sumD = sum(d.shape[1] for d in data)
+    flags = (rng.random((Cn, sumD)) < 0.7).astype(np.uint8) if rng.random() < 0.3 else None
+    seed = int(rng.integers(0, 2**31))
+    desc = f"K={K} n={n} N={N} P={P} C={Cn} q1={q1} T={block} n1={n1} it={iters} kinds={kinds} sep={sep} light={os.environ['PMDI_LIGHT_IDS']} vh={os.environ['PMDI_VERY_HEAVY']} flags={'y' if flags is not None else 'n'} seed={seed}"
+    try:
+        sw = pkg.Sweeper(data, kinds, N, P, n_chains=Cn, seed=seed, q1_mode=q1, block_threads=block)
+    except Exception as e:
+        return 0
+    orc = [O.Oracle(data, kinds, N, P, seed=seed + c, q1_mode=q1) for c in range(Cn)]
+    s = rng.integers(1, N + 1, size=(Cn, n, K))
+    Dcum = np.cumsum([d.shape[1] for d in data])[:-1]
+    for it in range(1, iters + 1):
+        order = np.stack([rng.permutation(n) + 1 for _ in range(Cn)])
+        hyp = []
+        for _ in range(Cn):
+            Pi = rng.gamma(1.0 / N, 1.0, size=(N, K)) + 1e-12; Pi /= Pi.sum(0)
+            hyp.append((Pi, rng.gamma(1.0, 0.2, size=max(1, K * (K - 1) // 2))))
+        r = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]), flags=flags)
+        for c in range(Cn):
+            o = orc[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1], flags=None if flags is None else np.split(flags[c], Dcum))
+            ok = (r["s"][c] == o["s"]).all() and int(r["p_star"][c]) == o["p_star"] and all(
+                r["stats"][c][key] == o["stats"][key] for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")) \
+                and np.allclose(r["logweight"][c], o["logweight"], rtol=1e-9, atol=1e-9)
+            if not ok:
+                raise AssertionError(f"MISMATCH: {desc} iteration {it} chain {c}")
+        s = r["s"].copy()
+    for o in orc: o.close()
+    sw.close()
+    return 1
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    n = run(budget, seed)
+    print(f"soak done: {n} random configurations, all equal to the oracle")
