@@ -30,6 +30,8 @@ def run(budget, seed, max_cases=10**9, verbose=True):
 def _one_case(rng):
     K = int(rng.integers(1, 4)); n = int(rng.integers(30, 220)); N = int(rng.integers(2, 21))
     P = int(rng.choice([2, 8, 33, 64, 200, 256, 512, 1024])); Cn = int(rng.integers(1, 5)); q1 = int(rng.integers(0, 2))
+    if os.environ.get("PMDI_SOAK_BIG"):       # fewer, larger cases: more particles, labels, datasets, observations
+        K = int(rng.integers(1, 5)); n = int(rng.integers(150, 500)); N = int(rng.integers(10, 51)); P = int(rng.choice([512, 1024, 2048, 4096]))
     block = int(rng.choice([0, 0, 0, 128, 256, 512, 1024])); n1 = int(rng.integers(1, n + 1)); iters = int(rng.integers(1, 5))
     os.environ["PMDI_LIGHT_IDS"] = str(int(rng.choice([2, 10, 40, 400])))
     os.environ["PMDI_VERY_HEAVY"] = str(int(rng.choice([0, 1, 2, 128])))
