@@ -94,6 +94,10 @@ __device__ __forceinline__ void lds_barrier()
 #ifndef PMDI_LIGHT_WPS
 #define PMDI_LIGHT_WPS 2
 #endif
+// pool reads in flight per lane in the statistics update of the 256-register wide build
+#ifndef PMDI_VH_U
+#define PMDI_VH_U 8
+#endif
 #ifndef PMDI_COLD_PREFIX
 #define PMDI_COLD_PREFIX __noinline__
 #endif
@@ -728,7 +732,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
                     }
                     PHS(13);
-                    stats_update_all<T, (T >= 512 && WPS <= 2) ? 8 : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
+                    stats_update_all<T, (T >= 512 && WPS <= 2) ? PMDI_VH_U : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
                         dl.get(j, src, dst, nnew);
                     });
                     new_ncls = (int)ccarry;
@@ -1425,7 +1429,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         s.cn[tgt] = nnew;
                         cl.set(0, 0, v);
                     }
-                    stats_update_all<T, (T >= 512 && WPS <= 2) ? 8 : 4>(d, s, flk, gen(sh.xs), 1, D, tid, [&](int, int &src, int &dst, int &nn) {
+                    stats_update_all<T, (T >= 512 && WPS <= 2) ? PMDI_VH_U : 4>(d, s, flk, gen(sh.xs), 1, D, tid, [&](int, int &src, int &dst, int &nn) {
                         src = c0; dst = tgt; nn = nnew;
                     });
                 }
@@ -1581,7 +1585,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         pidk[p] = sh.ktab_val[sidp[p]];
                     }
                 }
-                stats_update_all<T, (T >= 512 && WPS <= 2) ? 8 : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
+                stats_update_all<T, (T >= 512 && WPS <= 2) ? PMDI_VH_U : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
                     src = sh.fl_p[j]; dst = sh.fl_tgt[j]; nnew = sh.fl_nnew[j];
                 });
                 for (int j = tid; j < nk; j += T) sh.ktab_minp[sh.klist[j]] = PMDI_INF_I;
