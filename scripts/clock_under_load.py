@@ -1,3 +1,4 @@
+"""Shader clock (s_memtime vs wall clock) of the sweep kernel alone and with the GPU full: is it throttled under load?"""
 import os, sys
 os.environ["PMDI_PHASE_TIMERS"] = "1"
 import numpy as np, torch
