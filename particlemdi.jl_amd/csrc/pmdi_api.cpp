@@ -160,6 +160,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.Dmax = h->Dmax; a.sumD = h->sumD; a.npairs = h->npairs;
     a.q1 = h->cfg.q1_mode; a.q2 = h->cfg.q2_mode;
     a.terms_cap = h->terms_cap;
+    a.item_cap = h->cfg.N > 32 ? PMDI_ITEM_CAP_BIGN : PMDI_ITEM_CAP;
     a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.cost = (long long *)h->d_cost.p;

@@ -10,7 +10,8 @@
 // Compile-time capacities of the per-chain LDS tables (a step whose working set exceeds them
 // runs on the global-memory fallback).  Constants, so that the addresses of these tables fold
 // into instruction immediates instead of occupying registers.
-#define PMDI_ITEM_CAP 256   // (class, label) items of a step
+#define PMDI_ITEM_CAP 256   // (class, label) items of a fast-path step
+#define PMDI_ITEM_CAP_BIGN 384   // ... when N > 32 (N = 50: seven classes instead of five); must stay below PMDI_HT_SIZE
 #define PMDI_HT_SIZE 512    // entries per hash table (>= 2 * PMDI_ITEM_CAP, power of two)
 #define PMDI_CLS_LDS 128    // class-list slots per dataset kept in LDS
 #define PMDI_DL_LDS 128     // distinct-chosen-cluster entries kept in LDS (fallback path)
@@ -65,6 +66,7 @@ struct SweepArgs {
     int pid_lds;            // 1: particle class ids [K][P] live in LDS
     int pp_lds;             // 1: per-particle step scratch (sid, kv) lives in LDS
     int two_per_cu;         // 1: register-capped build so that two chains co-reside on a CU
+    int item_cap;           // (class, label) items a fast-path step may have: PMDI_ITEM_CAP, or PMDI_ITEM_CAP_BIGN when N > 32
     unsigned iter;
     long long n, n1;
     unsigned long long seed;

@@ -141,17 +141,6 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.leaf_tot = take(64 * 8);
     c.leaf_carry = take(64 * 8);
     c.leaf_prog = take(256);
-    c.lpl = take((size_t)PMDI_ITEM_CAP * 8);
-    c.cdf = take((size_t)(2 * PMDI_ITEM_CAP + 4) * 8);      // rows of N + 2: CDF, log-increment, one-hot label
-    c.need = take((size_t)PMDI_ITEM_CAP * 4);
-    c.need_slot = take((size_t)PMDI_ITEM_CAP * 4);
-    c.item_id = take((size_t)PMDI_ITEM_CAP * 4);
-    c.ktab_minp = take((size_t)PMDI_ITEM_CAP * 4);
-    c.ktab_val = take((size_t)PMDI_ITEM_CAP * 4);
-    c.klist = take((size_t)PMDI_ITEM_CAP * 4);
-    c.kl_v = take((size_t)PMDI_ITEM_CAP * 4);
-    c.kl_key = take((size_t)PMDI_ITEM_CAP * 4);
-    c.dl = take((size_t)3 * PMDI_DL_LDS * 4);
     c.dl_slot = take((size_t)PMDI_DL_LDS * 4);
     c.h1k = take((size_t)PMDI_HT_SIZE * 4);
     c.h1a = take((size_t)PMDI_HT_SIZE * 4);
@@ -162,6 +151,20 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.fl_slot = take((size_t)PMDI_HT_SIZE * 4);
     c.fl_nnew = take((size_t)PMDI_HT_SIZE * 4);
     c.fl_tgt = take((size_t)PMDI_HT_SIZE * 4);
+    // ---- tables of (class, label) items: a.item_cap entries each (256, or 384 when N > 32 so that more than
+    // five classes stay on the fast path); need .. dl are contiguous (the fallback step's cluster list) ----
+    const size_t icap = (size_t)a.item_cap;
+    c.lpl = take(icap * 8);
+    c.cdf = take((2 * icap + 4) * 8);                        // rows of N + 2: CDF, log-increment, one-hot label
+    c.need = take(icap * 4);
+    c.need_slot = take(icap * 4);
+    c.item_id = take(icap * 4);
+    c.ktab_minp = take(icap * 4);
+    c.ktab_val = take(icap * 4);
+    c.klist = take(icap * 4);
+    c.kl_v = take(icap * 4);
+    c.kl_key = take(icap * 4);
+    c.dl = take((size_t)3 * PMDI_DL_LDS * 4);
     // ---- sizes that depend on the configuration ----
     c.xs = take((size_t)a.Dmax * 8);
     c.pis = take((size_t)a.K * a.N * 8);
@@ -466,14 +469,14 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
 
 // The fallback step's list of distinct chosen clusters, (src id, updated id, new n) per entry.  The
 // fast path's tables are idle during a fallback step, so the list lives in two LDS regions of theirs
-// (need .. dl: 8 * PMDI_ITEM_CAP + 3 * PMDI_DL_LDS ints, contiguous; fl_p .. fl_tgt: 4 * PMDI_HT_SIZE ints)
-// and only what exceeds them (> 1 492 clusters) goes to the arena.  ktab_minp lies inside the first
+// (need .. dl: 8 * item_cap + 3 * PMDI_DL_LDS ints, contiguous; fl_p .. fl_tgt: 4 * PMDI_HT_SIZE ints)
+// and only what exceeds them (> 1 492 clusters at item_cap = 256) goes to the arena.  ktab_minp lies inside the first
 // region: the fallback step re-arms it (INF) before it returns.
 struct DList {
     lint a, b;
     gint g;
-    int P;
-    static constexpr int CA = (8 * PMDI_ITEM_CAP + 3 * PMDI_DL_LDS) / 3, CB = (4 * PMDI_HT_SIZE) / 3;
+    int P, CA;                                                 // CA = (8 * item_cap + 3 * PMDI_DL_LDS) / 3
+    static constexpr int CB = (4 * PMDI_HT_SIZE) / 3;
     __device__ __forceinline__ void set(int j, int src, int dst, int nnew) const
     {
         if (j < CA) { a[j] = src; a[CA + j] = dst; a[2 * CA + j] = nnew; }
@@ -555,7 +558,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
     const int items = ncls * N;
     const Dual<double> cdfp = dual(small, sh.cdf, s.cdf);
-    const DList dl{sh.need, sh.fl_p, s.dl, P};
+    const DList dl{sh.need, sh.fl_p, s.dl, P, (8 * a.item_cap + 3 * PMDI_DL_LDS) / 3};
     int nd = 0, nclone = 0, new_ncls = 0, failed = 0;
     (void)items;
     if (converted) {
@@ -740,7 +743,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                     for (int r = tid; r < new_ncls; r += T) sh.lead_of[cl.val(r)] = PMDI_INF_I;
                 }
     }
-    for (int e = tid; e < PMDI_ITEM_CAP; e += T) sh.ktab_minp[e] = PMDI_INF_I;     // it lies inside the list's LDS region
+    for (int e = tid; e < a.item_cap; e += T) sh.ktab_minp[e] = PMDI_INF_I;        // it lies inside the list's LDS region
     if (tid == 0) {
         sh.misc[M_NCLONE] = nclone; sh.misc[M_NCLS] = new_ncls;
         sh.khint[k] = (gcensus && nd > PMDI_HT_SIZE / 4) ? 1 : 0;   // stay on the global census while it is needed
@@ -1097,7 +1100,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     for (int p = tid; p < P; p += T) sh.lw[p] = a.lw_init;
     for (int c = tid; c <= P; c += T) { sh.lead_of[c] = PMDI_INF_I; sh.slot_of[c] = 0; }
     for (int e = tid; e < H; e += T) { sh.h1.key[e] = 0; sh.h1.a[e] = 0; sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
-    for (int e = tid; e < PMDI_ITEM_CAP; e += T) sh.ktab_minp[e] = PMDI_INF_I;
+    for (int e = tid; e < a.item_cap; e += T) sh.ktab_minp[e] = PMDI_INF_I;
     for (int e = tid; e < 2 * ((P >> 6) + 1); e += T) { sh.bm_fresh[e] = 0; sh.bm_clone[e] = 0; }
 
     sweep_prefix<T>(ap);
@@ -1139,7 +1142,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             const double *pik = gen(sh.pis + k * N);
             const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
             const int items = ncls * N;
-            const bool small = items <= PMDI_ITEM_CAP;
+            const bool small = items <= a.item_cap;
             if (ncls != 1) lw_uniform = false;
 
             PH(1);
