@@ -129,7 +129,11 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.red = take(48 * 8);
     c.misc = take(16 * 4);
     c.ph = take(16 * 8);
+#ifdef PMDI_RESAMPLE_TIMERS
+    c.stat = take(24 * 8);
+#else
     c.stat = take(8 * 8);
+#endif
     c.kmaxid = take(PMDI_KMAX_I * 4);
     c.kncls = take(PMDI_KMAX_I * 4);
     c.kcur = take(PMDI_KMAX_I * 4);
@@ -759,12 +763,20 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
     // (no phase-timer references in here: a __noinline__ function that takes the address of the step
     // loop's timer variables pins them in memory and costs the 128-register build ~50 more spill slots)
     PMDI_PREAMBLE;
+#ifdef PMDI_RESAMPLE_TIMERS      // A/B builds only: where does a resampling event spend its time?  (slots 0..7 of sh.stat are
+                                 // the counters; the timer state sits in slots of sh.ph that the sweep does not use here)
+#define PHR(i_) do { if (a.phase && tid == 0) { const long long t_ = clock64(); sh.stat[8 + (i_)] += t_ - rs_last; rs_last = t_; } } while (0)
+    long long rs_last = clock64();
+#else
+#define PHR(i_) do { } while (0)
+#endif
             // draw_partstar (src/misc.jl:27-47)
             const double u01 = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
             const double usl = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
             double *wb = gen(sh.term);
             for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
             __syncthreads();
+            PHR(0);   // weights
             // cumsum (:29) in Julia's accumulate_pairwise! order, bit-exactly but in parallel: the
             // recursion splits [1, P) into leaves of < 128 elements; a leaf's running sums s_ do not
             // depend on its carry, so (1) one lane per leaf forms them, (2) one lane walks the tree
@@ -848,6 +860,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 for (int i = i1 + lane; i < i1 + nn; i += 64) wb[i] = sc + wb[i];
             }
             __syncthreads();
+            PHR(1);   // cumsum + u sequence
             const double last = wb[P - 1];
             for (int j = tid; j < P; j += T) {
                 const double uj = usc[j];
@@ -866,6 +879,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             const Dual<int> ancp = dual(a.pp_lds != 0, sh.kv, make_ks(a.ds[0], chain).kv);
             for (int p = tid; p < P; p += T) ancp[p] = (p == 0) ? 0 : (p <= js ? pstar_raw[p - 1] : pstar_raw[p]);
             __syncthreads();
+            PHR(2);   // search + ancestors
             for (int k = 0; k < K; ++k) {                         // src/pmdi.jl:320-340
                 const DsetDev &d = a.ds[k];
                 const KS s = make_ks(d, chain);
@@ -881,6 +895,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 // otherwise the per-id scratch tables in global memory
                 const bool lm = oldmax + 1 <= 2 * a.terms_cap;
                 lint lmap = (lint)sh.term;
+                PHR(3);   // (dataset loop top)
                 if (lm) for (int e = tid; e <= oldmax; e += T) lmap[e] = 0;
                 for (int id = 1 + tid; id <= oldmax; id += T) s.counts[id] = 0;   // (:326)
                 __syncthreads();
@@ -904,6 +919,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                     }
                 }
                 __syncthreads();
+                PHR(4);   // gather
                 for (int p = tid; p < P; p += T) pidk[p] = (int)sidp[p];
                 // sort(unique(particle)) ascending -> 1..U' (:329): scan of live marks
                 unsigned long long carry = 0;
@@ -916,6 +932,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                     carry += tot;
                 }
                 const int newmax = (int)carry;
+                PHR(5);   // id scan
                 // relabel + recount (:331-338); the histogram lives in LDS (the hash/list tables are
                 // idle here) when the renumbered ids fit, with wave-aggregated adds either way
                 lint hist = sh.h1.key;                            // 9 * PMDI_HT_SIZE contiguous ints
@@ -948,12 +965,14 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                     }
                 }
                 __syncthreads();
+                PHR(6);   // relabel + recount
                 if (lhist) {
                     for (int e = 1 + tid; e <= newmax; e += T) s.counts[e] = hist[e];
                     __syncthreads();
                     for (int e = tid; e < 9 * PMDI_HT_SIZE; e += T)       // tables back to empty (h2.b = INF)
                         hist[e] = (e >= 4 * PMDI_HT_SIZE && e < 5 * PMDI_HT_SIZE) ? PMDI_INF_I : 0;
                 }
+                PHR(7);   // counts copy + table reset
                 if (moves) {
                     // clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending (:336):
                     // batches in ascending order, load -> barrier -> store
@@ -1005,10 +1024,13 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 __syncthreads();
                 if (!lm) for (int id = 1 + tid; id <= oldmax; id += T) { s.ncop[id] = 0; s.firstc[id] = PMDI_INF_I; }
                 __syncthreads();
+                PHR(8);   // moves
                 const int nc2 = rebuild_classes<T>(pidk, cl, sh, P);
                 if (tid == 0) { sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1; }
                 __syncthreads();
+                PHR(9);   // classes
             }
+#undef PHR
 }
 
 // particle pick (src/pmdi.jl:345-350), s = sstar[p_star,:,:] (:373), counters
@@ -1081,7 +1103,12 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || (int)blockIdx.x < a.rank_lo || (int)blockIdx.x >= a.rank_hi)) return;
 
     const long long t_start = clock64();
-    if (tid < 8) sh.stat[tid] = 0;    // the sweep's counters live in LDS, kept by lane 0: eight 64-bit values less across
+#ifdef PMDI_RESAMPLE_TIMERS
+    if (tid < 24) sh.stat[tid] = 0;
+#else
+    if (tid < 8) sh.stat[tid] = 0;
+#endif
+       // the sweep's counters live in LDS, kept by lane 0: eight 64-bit values less across
                                       // the step loop (the 128-register build: 158 -> 124 spill slots)
     long long ph_last = 0;
     int ph_cur = 0;
@@ -1680,6 +1707,10 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     }
     __syncthreads();
     if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
+#ifdef PMDI_RESAMPLE_TIMERS
+    __syncthreads();
+    if (a.phase && tid < 10) a.phase[(size_t)chain * 16 + tid] = sh.stat[8 + tid];   // A/B build: resampling sub-phases instead
+#endif
 }
 
 // Launch order for the next sweep: chains sorted by the cycles their last sweep took, heaviest

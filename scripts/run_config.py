@@ -35,6 +35,12 @@ for it in range(1, iters + 1):
     print(f"it {it}: sweep {dt*1e3:9.1f} ms (host hypers {th*1e3:.0f} ms, align {ta*1e3:.0f} ms) ids/step {np.mean([s['n_operations'] for s in st])/(ns*K):8.1f} cls/step {np.mean([s['sum_classes'] for s in st])/(ns*K):6.2f} "
           f"resamples {np.mean([s['n_resamples'] for s in st]):6.1f} fast/conv/slow {np.mean([s['steps_fast'] for s in st]):.0f}/{np.mean([s['steps_converted'] for s in st]):.0f}/{np.mean([s['steps_fallback'] for s in st]):.0f} nclust {[len(np.unique(hys[0].s[:,k])) for k in range(K)]}", flush=True)
     if os.environ.get("PMDI_PHASE_TIMERS"):
+        if os.environ.get("PMDI_RESAMPLE_SUBPHASES"):    # library built with -DPMDI_RESAMPLE_TIMERS: the slots hold resampling sub-phases
+            rn = ["weights", "cumsum+u", "search+ancestors", "dataset top", "gather", "id scan", "relabel+recount", "counts copy+reset", "moves", "classes"]
+            ph = sw.phase_timers(0).astype(np.float64)[:10]
+            nres = max(1, st[0]["n_resamples"])
+            print("   resampling, cycles per event: " + " ".join(f"{nm}={v/nres:.0f}" for nm, v in zip(rn, ph)) + f" | total {ph.sum()/nres:.0f}", flush=True)
+            continue
         names = ["setup+prefix", "stage+needlist", "terms", "sums", "cdf", "C:draw+vote+census", "D1:keys+firsts", "D2:ranks", "E:apply+stats", "phi+ess+looptop", "resample", "final", "slow:draw/census", "slow:stats|unanimous"]
         ph = sw.phase_timers(0).astype(np.float64)[:14]
         print("   chain 0: " + " ".join(f"{nm}={100*v/ph.sum():.1f}%" for nm, v in zip(names, ph) if v > 0.004 * ph.sum()) + f" | cycles/step {ph.sum()/(ns*K):.0f}", flush=True)
