@@ -214,7 +214,7 @@ __device__ __forceinline__ bool wave_group(int key, bool valid, int &count)
     count = 0;
     while (active) {
         int l0 = __ffsll((long long)active) - 1;
-        int k0 = __shfl(key, l0);
+        int k0 = __builtin_amdgcn_readlane(key, l0);   // l0 is wave-uniform: v_readlane, not a ds_bpermute round trip
         unsigned long long m = __ballot(valid && key == k0);
         if (lane == l0) { leader = true; count = __popcll(m); }
         active &= ~m;
@@ -232,7 +232,7 @@ __device__ __forceinline__ int wave_group_lead(int key, bool valid, int &count)
     count = 0;
     while (active) {
         const int l0 = __ffsll((long long)active) - 1;
-        const int k0 = __shfl(key, l0);
+        const int k0 = __builtin_amdgcn_readlane(key, l0);
         const bool mine = valid && key == k0;
         const unsigned long long m = __ballot(mine);
         if (mine) lead = l0;

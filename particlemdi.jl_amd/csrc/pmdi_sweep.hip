@@ -1473,7 +1473,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     int c = 0, kidx = 0;
                     if (valid) { c = kvp[p]; kidx = sidp[p]; }
                     const unsigned long long vmask = __ballot(valid);
-                    const int k0 = __shfl(kidx, 0), c0w = __shfl(c, 0);
+                    const int k0 = __builtin_amdgcn_readlane(kidx, 0), c0w = __builtin_amdgcn_readlane(c, 0);
                     int slot = -1;
                     if (__all(!valid || (kidx == k0 && c == c0w))) {     // the whole wave agrees: one lane speaks
                         if (lane == 0 && valid) {
@@ -1483,7 +1483,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                             if (slot < 0) sh.misc[M_OVF] = 1;
                             else { atomicAdd(gen(&sh.h2.a[slot]), __popcll(vmask)); atomicMin(gen(&sh.h2.b[slot]), p); }
                         }
-                        slot = __shfl(slot, 0);
+                        slot = __builtin_amdgcn_readlane(slot, 0);
                     } else {
                         if (valid) atomicMin(gen(&sh.ktab_minp[kidx]), p);
                         int cnt;
