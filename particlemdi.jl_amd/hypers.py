@@ -145,6 +145,60 @@ class HyperState:
 
     # -- align_labels! (src/misc.jl:61-96) ------------------------------------
     def align_labels(self):
+        """align_labels! through N x N contingency tables.  The reference recounts
+        `count_equals(label_rows, ...)` over the n observations for every (label, new_label) pair; the
+        counts it needs are entries of T[k][j][a, b] = #{i : s[i, k] == a and s[i, j] == b}:
+            count_equals(label_rows, label)[j]     = T[k][j][label, label]
+            count_equals(new_rows, new_label)[j]   = T[k][j][new, new]
+            count_equals(label_rows, new_label)[j] = T[k][j][label, new]
+            count_equals(new_rows, label)[j]       = T[k][j][new, label]
+        and an accepted swap exchanges two rows of T[k][j] (and two columns of T[j][k]).  Same integers,
+        same floating-point expressions in the same order, same random numbers consumed: the result is
+        identical to `_align_labels_by_recount` (the line-by-line restatement, kept as the test oracle)."""
+        K, N = self.K, self.N
+        if K == 1:
+            return
+        s, gam = self.s, self.gamma
+        phi_log = np.log(self.Phi + 1.0)
+        z = s - 1
+        T = {(k, j): np.bincount(z[:, k] * N + z[:, j], minlength=N * N).reshape(N, N).astype(np.int64)
+             for k in range(K) for j in range(K) if j != k}
+        for k in range(K):
+            others = [j for j in range(K) if j != k]
+            rel = np.array([phi_log[i] for i in range(self.npairs)
+                            if self.pairs[i][0] == k or self.pairs[i][1] == k])
+            col = s[:, k]
+            _, first = np.unique(col, return_index=True)
+            occupied = col[np.sort(first)].tolist()                          # unique(), first appearance
+            perm = np.arange(N + 1)                                          # label of the start of this k -> label now
+            for label in occupied:
+                a = label - 1
+                if T[(k, others[0])][a].sum() == 0:                          # all(label_ind .== false)
+                    continue
+                for new_label in range(1, N + 1):
+                    if new_label == label:
+                        continue
+                    b = new_label - 1
+                    c_ll = np.array([T[(k, j)][a, a] for j in others], dtype=np.float64)
+                    c_nn = np.array([T[(k, j)][b, b] for j in others], dtype=np.float64)
+                    c_ln = np.array([T[(k, j)][a, b] for j in others], dtype=np.float64)
+                    c_nl = np.array([T[(k, j)][b, a] for j in others], dtype=np.float64)
+                    lps = (c_ll * rel + c_nn * rel).sum()
+                    lps_swap = (c_ln * rel + c_nl * rel).sum()
+                    with np.errstate(over="ignore"):
+                        accept = np.exp(lps_swap - lps)
+                    if self.rng.random() < accept:
+                        for j in others:
+                            T[(k, j)][[a, b], :] = T[(k, j)][[b, a], :]
+                            T[(j, k)][:, [a, b]] = T[(j, k)][:, [b, a]]
+                        ia, ib = perm == label, perm == new_label
+                        perm[ia], perm[ib] = new_label, label
+                        gam[b, k], gam[a, k] = gam[a, k], gam[b, k]
+                        label = new_label
+                        a = label - 1
+            s[:, k] = perm[col]
+
+    def _align_labels_by_recount(self):
         K, N = self.K, self.N
         if K == 1:
             return

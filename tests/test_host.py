@@ -134,3 +134,24 @@ def test_psm_rows_matches_reference_definition(pkg):
     np.fill_diagonal(want, 1.0)
     assert np.allclose(full[K], want)
     assert np.allclose(np.concatenate([psm_rows(samples, 0, 5), psm_rows(samples, 5, n)], axis=1), full)
+
+
+def test_align_labels_tables_equal_the_recount(pkg):
+    # the contingency-table form makes the same decisions as the line-by-line restatement
+    import copy
+    from particlemdi_jl_amd.hypers import HyperState
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        n, N, K = 180 + 17 * seed, 4 + seed, 2 + seed % 3
+        hy = HyperState(n, N, K, np.random.default_rng(100 + seed))
+        z = rng.integers(1, N + 1, n)
+        for k in range(K):       # correlated allocations with permuted labels: swaps do get accepted
+            p = rng.permutation(N) + 1
+            hy.s[:, k] = np.where(rng.random(n) < 0.8, p[z - 1], rng.integers(1, N + 1, n))
+        hy.Phi[:] = rng.gamma(2.0, 2.0, size=hy.Phi.shape)
+        a, b = copy.deepcopy(hy), copy.deepcopy(hy)
+        a.align_labels()
+        b._align_labels_by_recount()
+        assert (a.s == b.s).all() and (a.gamma == b.gamma).all()
+        assert a.rng.random() == b.rng.random()          # same number of uniforms consumed
+        assert not (a.s == hy.s).all()                    # and something did move
