@@ -41,16 +41,19 @@ def psm_counts_device(samples, row_lo, row_hi, n_labels=0):
     return out
 
 
-def psm_rows(samples, row_lo, row_hi, n_labels=0):
+def psm_rows(samples, row_lo, row_hi, n_labels=0, host=False):
     """Rows [row_lo, row_hi) of the K (+1) posterior-similarity matrices from pooled samples
     (S, K, n); lower triangle as the reference fills it, identity elsewhere.  Works on torch
-    tensors (any device) or numpy arrays.  The rows of a matrix are independent, so ranks
+    tensors or numpy arrays.  CUDA tensors go through the HIP kernels (pmdi_psm_counts_device); host data is only
+    accepted with host=True (the plain-torch mirror used by the CPU tests and the gloo rehearsal).  The rows of a matrix are independent, so ranks
     split them with no further exchange."""
     is_np = isinstance(samples, np.ndarray)
-    if is_np:
-        import torch
-        samples = torch.from_numpy(samples)
     import torch
+    if is_np:
+        samples = torch.from_numpy(samples)
+    if not samples.is_cuda and not host:
+        # no silent CPU path: the counts come from the HIP kernels unless the caller asks for the host mirror
+        raise ValueError("psm_rows: samples are not on an MI355X; pass host=True for the host mirror (tests, gloo rehearsal)")
     S, K, n = samples.shape
     out = torch.zeros((K + (1 if K > 1 else 0), row_hi - row_lo, n), dtype=torch.float64, device=samples.device)
     rows = torch.arange(row_lo, row_hi, device=samples.device)

@@ -35,7 +35,7 @@ def _worker(rank, world, port, outdir):
     pooled = allgather_samples(mine)                              # the one collective of the path
     assert pooled.shape == (world * T * C, K, n)
     lo, hi = rank * n // world, (rank + 1) * n // world           # PSM rows are partitioned, no further exchange
-    rows = psm_rows(pooled, lo, hi)
+    rows = psm_rows(pooled, lo, hi, host=True)
     np.save(os.path.join(outdir, f"rows{rank}.npy"), rows.numpy())
     np.save(os.path.join(outdir, f"mine{rank}.npy"), mine.numpy())
     dist.barrier()
@@ -52,6 +52,6 @@ def test_allgather_and_psm_two_ranks(tmp_path):
     from particlemdi_jl_amd.psm import psm_rows
     mine = [np.load(tmp_path / f"mine{r}.npy") for r in range(world)]
     pooled = np.concatenate([m.reshape(-1, m.shape[-2], m.shape[-1]) for m in mine])
-    want = psm_rows(pooled, 0, pooled.shape[-1])
+    want = psm_rows(pooled, 0, pooled.shape[-1], host=True)
     got = np.concatenate([np.load(tmp_path / f"rows{r}.npy") for r in range(world)], axis=1)
     assert np.allclose(got, want)

@@ -134,5 +134,5 @@ def test_psm_counts_on_device(pkg, O, S, K, n, lo, hi, nlab):
     assert (got == O.psm_counts(smp, lo, hi)).all()
     # and the posterior-similarity rows built from it equal the host mirror's
     rows_dev = psm.psm_rows(torch.from_numpy(smp).cuda(), lo, hi, n_labels=nlab).cpu().numpy()
-    rows_host = psm.psm_rows(smp, lo, hi)
+    rows_host = psm.psm_rows(smp, lo, hi, host=True)
     assert (rows_dev == rows_host).all()

@@ -123,7 +123,7 @@ def test_psm_rows_matches_reference_definition(pkg):
     rng = np.random.default_rng(5)
     S, K, n = 7, 2, 12
     samples = rng.integers(1, 4, size=(S, K, n)).astype(np.uint8)
-    full = psm_rows(samples, 0, n)
+    full = psm_rows(samples, 0, n, host=True)
     assert full.shape == (K + 1, n, n)
     for k in range(K):
         for j in range(n - 1):
@@ -133,7 +133,7 @@ def test_psm_rows_matches_reference_definition(pkg):
     want = np.eye(n) + sum(full[k] for k in range(K)) / K
     np.fill_diagonal(want, 1.0)
     assert np.allclose(full[K], want)
-    assert np.allclose(np.concatenate([psm_rows(samples, 0, 5), psm_rows(samples, 5, n)], axis=1), full)
+    assert np.allclose(np.concatenate([psm_rows(samples, 0, 5, host=True), psm_rows(samples, 5, n, host=True)], axis=1), full)
 
 
 def test_align_labels_tables_equal_the_recount(pkg):
