@@ -91,6 +91,15 @@ typedef struct {
 /* Replaces the allocations of src/pmdi.jl:99-146 and the null-cluster
  * marginal of :120-128.  Copies the data to the device (row-major). */
 int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handle **out);
+
+/* Tuning knobs read from the environment at pmdi_create (results never depend on them):
+ *   PMDI_SPLIT=0          one launch per sweep instead of the heaviest / heavy / light launches (block_threads = 0)
+ *   PMDI_LIGHT_IDS=40     a chain whose last sweep met at most this many live clusters per step is "light"
+ *   PMDI_VERY_HEAVY=128   how many of the heaviest chains get a CU each
+ *   PMDI_HEAVY_T          workgroup width of the heavy group (512 or 1024)
+ *   PMDI_TWO_PER_CU=0     256-register builds everywhere (one wide chain per CU)
+ *   PMDI_TERMS_CAP        LDS doubles for the per-feature terms
+ *   PMDI_PHASE_TIMERS=1   per-stage shader-clock timers (pmdi_phase_timers) */
 int pmdi_destroy(pmdi_handle *h);
 const char *pmdi_last_error(void);
 int pmdi_abi_version(void);
