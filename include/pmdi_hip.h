@@ -198,6 +198,52 @@ int pmdi_label_counts_device(pmdi_handle *h, const int32_t *s, int32_t *counts, 
 int pmdi_psm_counts_device(int32_t device, const uint8_t *samples, int64_t S, int32_t K, int64_t n,
                            int64_t row_lo, int64_t row_hi, int32_t n_labels, int32_t *counts, void *stream);
 
+/* ---- device-resident Gibbs chains -----------------------------------------
+ * Everything pmdi() does per iteration AROUND the sweep, for every chain of the handle, without leaving the
+ * device: shuffle!(order_obs) (src/pmdi.jl:172), update_M!, update_gamma!, Pi, update_Phi!, update_Z, update_v
+ * (src/pmdi.jl:176-185, src/update_hypers.jl) evaluated WITHOUT the N^K tables of src/pmdi.jl:69-92, and
+ * align_labels! (src/pmdi.jl:375, src/misc.jl:61-96) through N x N contingency tables.  The stale Gamma_c of
+ * the reference (built once from the initial gamma, src/pmdi.jl:75-79) is kept.  Host-side draws of the
+ * reference (Julia's global RNG) become counter-based Philox variates keyed on (seed + chain, iteration, site).
+ * pmdi_gibbs_create replaces src/pmdi.jl:59-66, 95-96, 106-110, 160-161. */
+typedef struct pmdi_gibbs pmdi_gibbs;
+int pmdi_gibbs_create(pmdi_handle *h, double rho, int32_t feature_select, pmdi_gibbs **out);
+int pmdi_gibbs_destroy(pmdi_gibbs *g);      /* before pmdi_destroy of its handle */
+
+/* n_iter iterations of src/pmdi.jl:164-384 for every chain, asynchronously on `stream` (hipStream_t, verbatim).
+ * samples: NULL, or device memory for n_iter x n_chains x K x n bytes: the allocations after each iteration
+ * (0-based labels), i.e. the rows generate_psm reads back from the CSV (consensus_map.jl:31-46). */
+int pmdi_gibbs_iterate(pmdi_gibbs *g, int64_t n_iter, uint8_t *samples, void *stream);
+
+/* The pieces of one iteration as separate launches (tests; a host that wants to interleave its own work).
+ * Order inside pmdi(): BEGIN (iteration counter += 1), HYPERS (:172-185), SWEEP (:165-171,188-350,373),
+ * FEATSEL (:354-370, only with feature selection), ALIGN (:375). */
+enum { PMDI_STEP_BEGIN = 0, PMDI_STEP_HYPERS = 1, PMDI_STEP_SWEEP = 2, PMDI_STEP_FEATSEL = 3, PMDI_STEP_ALIGN = 4 };
+int pmdi_gibbs_step(pmdi_gibbs *g, int32_t what, void *stream);
+int64_t pmdi_gibbs_iterations(const pmdi_gibbs *g);
+
+/* Host copies of one chain's state in the reference's shapes (any pointer may be NULL): M[K], gamma and gamma0
+ * N x K column-major (gamma0 = exp.(Gamma_c) rows, the initial gamma), Phi[max(1,K(K-1)/2)], vZ = (v, Z),
+ * s n x K column-major Int64 labels 1..N, order_obs n Int64 1-based, feature_flag sum_k D_k bytes. */
+int pmdi_gibbs_get(pmdi_gibbs *g, int32_t chain, double *M, double *gamma, double *gamma0, double *Phi, double *vZ,
+                   int64_t *s, int64_t *order_obs, uint8_t *feature_flag);
+int pmdi_gibbs_set(pmdi_gibbs *g, int32_t chain, const double *M, const double *gamma, const double *gamma0,
+                   const double *Phi, const double *vZ, const int64_t *s, const int64_t *order_obs,
+                   const uint8_t *feature_flag);
+/* Counters and outputs of the last sweep for all chains (synchronises): stats n_chains x 8 Int64 (layout of
+ * pmdi_sweep_stats), err per chain, p_star 1-based, logweight n_chains x P.  Fails if a chain reported an error. */
+int pmdi_gibbs_results(pmdi_gibbs *g, int64_t *stats, int32_t *err, int64_t *p_star, double *logweight);
+
+/* Device pointers of the resident state (zero-copy consumers; layouts of pmdi_sweep_device). */
+typedef struct {
+    double *M, *gamma, *gamma0, *Phi, *vZ, *Pi, *log1p_phi, *feature_prob, *logweight;
+    int32_t *s, *order_obs, *p_star, *err;
+    int64_t *stats;
+    uint8_t *feature_flag;
+    int64_t n1;
+} pmdi_gibbs_view;
+int pmdi_gibbs_device_view(pmdi_gibbs *g, pmdi_gibbs_view *v);
+
 /* Debug: per-phase shader-clock totals of the last sweep (lane 0 of the chain's workgroup);
  * only when the environment variable PMDI_PHASE_TIMERS was set at pmdi_create. */
 int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);

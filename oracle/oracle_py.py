@@ -17,10 +17,9 @@ KIND_BY_NAME = {"gaussian": GAUSSIAN, "categorical": CATEGORICAL, "negbinom": NE
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "pmdi_oracle.c")
-    hdr = os.path.join(_HERE, "pmdi_oracle.h")
+    deps = [os.path.join(_HERE, f) for f in ("pmdi_oracle.c", "pmdi_oracle_hypers.c", "pmdi_oracle.h", "Makefile")]
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "libpmdi_oracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -78,6 +77,28 @@ def lib():
     L.pmdi_oracle_philox4x32_10.argtypes = [vp, vp, vp]
     L.pmdi_oracle_uniform.restype = dbl
     L.pmdi_oracle_uniform.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.pmdi_oracle_hypers_create.restype = vp
+    L.pmdi_oracle_hypers_create.argtypes = [i64, i32, i32, u64]
+    L.pmdi_oracle_hypers_destroy.argtypes = [vp]
+    for f in ("update_M", "update_gamma", "update_Phi", "align_labels", "shuffle"):
+        getattr(L, "pmdi_oracle_hypers_" + f).restype = None
+        getattr(L, "pmdi_oracle_hypers_" + f).argtypes = [vp, i64]
+    L.pmdi_oracle_hypers_update_Z.restype = dbl
+    L.pmdi_oracle_hypers_update_Z.argtypes = [vp]
+    L.pmdi_oracle_hypers_update_v.restype = dbl
+    L.pmdi_oracle_hypers_update_v.argtypes = [vp, i64]
+    L.pmdi_oracle_hypers_step.restype = None
+    L.pmdi_oracle_hypers_step.argtypes = [vp, i64, vp]
+    L.pmdi_oracle_hypers_get.argtypes = [vp, C.c_int, vp]
+    L.pmdi_oracle_hypers_set.argtypes = [vp, C.c_int, vp]
+    L.pmdi_oracle_hypers_s.restype = C.POINTER(C.c_int64)
+    L.pmdi_oracle_hypers_s.argtypes = [vp]
+    L.pmdi_oracle_hypers_order.restype = C.POINTER(C.c_int64)
+    L.pmdi_oracle_hypers_order.argtypes = [vp]
+    L.pmdi_oracle_normal.restype = dbl
+    L.pmdi_oracle_normal.argtypes = [u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.pmdi_oracle_gamma.restype = dbl
+    L.pmdi_oracle_gamma.argtypes = [dbl, u64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     _lib = L
     return L
 
@@ -278,3 +299,72 @@ def philox(ctr, key):
 
 def uniform(seed, it, pos, k, p, site):
     return lib().pmdi_oracle_uniform(int(seed), it, pos, k, p, site)
+
+
+class Hypers:
+    """M, gamma, Phi, v, Z, s, order_obs of one chain and the per-iteration host work around the sweep
+    (oracle/pmdi_oracle_hypers.c: src/pmdi.jl:59-96,172-185, src/update_hypers.jl, align_labels!), with the
+    reference's N^K tables kept literally."""
+
+    def __init__(self, n, N, K, seed=0):
+        self.L = lib()
+        self.n, self.N, self.K = int(n), int(N), int(K)
+        self.npairs = max(1, K * (K - 1) // 2)
+        self.h = self.L.pmdi_oracle_hypers_create(self.n, self.N, self.K, int(seed))
+        if not self.h:
+            raise ValueError("pmdi_oracle_hypers_create rejected the configuration (N^K too large?)")
+        self.s = np.ctypeslib.as_array(self.L.pmdi_oracle_hypers_s(self.h), shape=(self.K, self.n)).T      # (n, K) view
+        self.order = np.ctypeslib.as_array(self.L.pmdi_oracle_hypers_order(self.h), shape=(self.n,))
+
+    def close(self):
+        if self.h:
+            self.s = self.order = None
+            self.L.pmdi_oracle_hypers_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _get(self, what, size):
+        out = np.zeros(size)
+        self.L.pmdi_oracle_hypers_get(self.h, what, _ptr(out))
+        return out
+
+    def _set(self, what, v):
+        a = np.ascontiguousarray(v, dtype=np.float64)
+        self.L.pmdi_oracle_hypers_set(self.h, what, _ptr(a))
+
+    M = property(lambda self: self._get(0, self.K), lambda self, v: self._set(0, v))
+    # gamma, gamma0: (N, K)
+    gamma = property(lambda self: self._get(1, self.N * self.K).reshape(self.K, self.N).T,
+                     lambda self, v: self._set(1, np.asarray(v, dtype=np.float64).T))
+    Phi = property(lambda self: self._get(2, self.npairs), lambda self, v: self._set(2, v))
+    gamma0 = property(lambda self: self._get(4, self.N * self.K).reshape(self.K, self.N).T,
+                      lambda self, v: self._set(4, np.asarray(v, dtype=np.float64).T))
+    v = property(lambda self: self._get(3, 2)[0], lambda self, x: self._set(3, [x, self._get(3, 2)[1]]))
+    Z = property(lambda self: self._get(3, 2)[1], lambda self, x: self._set(3, [self._get(3, 2)[0], x]))
+
+    def update_M(self, it): self.L.pmdi_oracle_hypers_update_M(self.h, int(it))
+    def update_gamma(self, it): self.L.pmdi_oracle_hypers_update_gamma(self.h, int(it))
+    def update_Phi(self, it): self.L.pmdi_oracle_hypers_update_Phi(self.h, int(it))
+    def update_Z(self): return self.L.pmdi_oracle_hypers_update_Z(self.h)
+    def update_v(self, it): return self.L.pmdi_oracle_hypers_update_v(self.h, int(it))
+    def align_labels(self, it): self.L.pmdi_oracle_hypers_align_labels(self.h, int(it))
+    def shuffle(self, it): self.L.pmdi_oracle_hypers_shuffle(self.h, int(it))
+
+    def step(self, it):
+        """shuffle!, update_M!, update_gamma!, Pi, update_Phi!, update_Z, update_v (src/pmdi.jl:172-185); returns Pi (N, K)."""
+        Pi = np.zeros((self.K, self.N))
+        self.L.pmdi_oracle_hypers_step(self.h, int(it), _ptr(Pi))
+        return Pi.T.copy()
+
+
+def normal(seed, it, pos, k, p0, site):
+    return lib().pmdi_oracle_normal(int(seed), it, pos, k, p0, site)
+
+
+def gamma(shape, seed, it, pos, k, site):
+    return lib().pmdi_oracle_gamma(float(shape), int(seed), it, pos, k, site)

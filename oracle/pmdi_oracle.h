@@ -119,6 +119,31 @@ void pmdi_oracle_phi_upweight(double *logweight, const int64_t *sstar_i,
 void pmdi_oracle_psm_counts(const uint8_t *samples, int64_t S, int32_t K, int64_t n,
                             int64_t row_lo, int64_t row_hi, int32_t *counts);
 
+/* --- the per-iteration host work around the sweep (oracle/pmdi_oracle_hypers.c) -------------
+ * Literal restatement (N^K tables and all) of src/update_hypers.jl, align_labels! (src/misc.jl:61-96),
+ * shuffle!(order_obs) (src/pmdi.jl:172) and the initialisation of src/pmdi.jl:59-96, driven by
+ * counter-based Philox draws.  Checks the factorised device kernels of csrc/pmdi_hypers.hip. */
+typedef struct pmdi_oracle_hypers pmdi_oracle_hypers;
+pmdi_oracle_hypers *pmdi_oracle_hypers_create(int64_t n, int32_t N, int32_t K, uint64_t seed); /* pmdi.jl:59-96 */
+void pmdi_oracle_hypers_destroy(pmdi_oracle_hypers *h);
+void pmdi_oracle_hypers_update_M(pmdi_oracle_hypers *h, int64_t iter);      /* update_hypers.jl:5-26 */
+void pmdi_oracle_hypers_update_gamma(pmdi_oracle_hypers *h, int64_t iter);  /* update_hypers.jl:64-92 */
+void pmdi_oracle_hypers_update_Phi(pmdi_oracle_hypers *h, int64_t iter);    /* update_hypers.jl:95-128 */
+double pmdi_oracle_hypers_update_Z(pmdi_oracle_hypers *h);                  /* update_hypers.jl:29-39 */
+double pmdi_oracle_hypers_update_v(pmdi_oracle_hypers *h, int64_t iter);    /* update_hypers.jl:1-3 */
+void pmdi_oracle_hypers_align_labels(pmdi_oracle_hypers *h, int64_t iter);  /* misc.jl:61-96 */
+void pmdi_oracle_hypers_shuffle(pmdi_oracle_hypers *h, int64_t iter);       /* pmdi.jl:172 */
+/* pmdi.jl:172-185 in pmdi()'s order; Pi: N x K column-major */
+void pmdi_oracle_hypers_step(pmdi_oracle_hypers *h, int64_t iter, double *Pi);
+/* what: 0 M[K], 1 gamma[N x K], 2 Phi[npairs], 3 (v, Z), 4 gamma0 = exp(Gamma_c) (the stale table) */
+int pmdi_oracle_hypers_get(const pmdi_oracle_hypers *h, int what, double *out);
+int pmdi_oracle_hypers_set(pmdi_oracle_hypers *h, int what, const double *in);
+int64_t *pmdi_oracle_hypers_s(pmdi_oracle_hypers *h);      /* n x K column-major, labels 1..N (live pointer) */
+int64_t *pmdi_oracle_hypers_order(pmdi_oracle_hypers *h);  /* n, 1-based (live pointer) */
+/* samplers: the specification shared with the HIP path */
+double pmdi_oracle_normal(uint64_t seed, uint32_t iter, uint32_t pos, uint32_t k, uint32_t p0, uint32_t site);
+double pmdi_oracle_gamma(double shape, uint64_t seed, uint32_t iter, uint32_t pos, uint32_t k, uint32_t site);
+
 /* --- counter-based RNG shared (as a specification) with the HIP path ---- */
 void pmdi_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double pmdi_oracle_uniform(uint64_t seed, uint32_t iter, uint32_t pos, uint32_t k,

@@ -12,7 +12,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PMDI_LIB_PATH") or os.path.join(_PKG, "libpmdi_hip.so")   # override: A/B builds only
-_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_api.cpp")]
+_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_hypers.hip", "pmdi_api.cpp")]
 _HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_PKG, "csrc", "pmdi_device.h"),
             os.path.join(_ROOT, "include", "pmdi_hip.h")]
 
@@ -29,21 +29,44 @@ EXPORTS = [
     "pmdi_clusters_free", "pmdi_cluster_add", "pmdi_calc_logprob", "pmdi_calc_logmarginal",
     "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L", "pmdi_phase_timers",
     "pmdi_block_threads", "pmdi_lds_bytes", "pmdi_chain_costs", "pmdi_label_counts_device", "pmdi_psm_counts_device",
+    "pmdi_gibbs_create", "pmdi_gibbs_destroy", "pmdi_gibbs_iterate", "pmdi_gibbs_step", "pmdi_gibbs_iterations",
+    "pmdi_gibbs_get", "pmdi_gibbs_set", "pmdi_gibbs_results", "pmdi_gibbs_device_view",
 ]
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = _SOURCES + _HEADERS
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(p) for p in deps)):
-        return LIB_PATH
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per
+    source under particlemdi.jl_amd/build/ (rebuilt when the source or a header is newer), then one link."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-           "-shared", "-o", LIB_PATH] + os.environ.get("PMDI_EXTRA_HIPCC_FLAGS", "").split() + _SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    extra = os.environ.get("PMDI_EXTRA_HIPCC_FLAGS", "").split()
+    bdir = os.path.join(_PKG, "build" if not os.environ.get("PMDI_LIB_PATH") else "build_ab")
+    os.makedirs(bdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(p) for p in _HEADERS)
+    stamp = os.path.join(bdir, "flags.txt")
+    flags_now = " ".join(extra)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
+    procs, objs = [], []
+    for src in _SOURCES:
+        obj = os.path.join(bdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time)):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-x", "hip",
+               "-c", src, "-o", obj] + extra
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    failed = [cmd for cmd, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    if procs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(flags_now)
     return LIB_PATH
 
 
@@ -135,6 +158,23 @@ def lib():
     L.pmdi_chain_costs.argtypes = [vp, vp]
     L.pmdi_phase_timers.restype = C.c_int
     L.pmdi_phase_timers.argtypes = [vp, i32, vp]
+    L.pmdi_gibbs_create.restype = C.c_int
+    L.pmdi_gibbs_create.argtypes = [vp, dbl, i32, C.POINTER(vp)]
+    L.pmdi_gibbs_destroy.argtypes = [vp]
+    L.pmdi_gibbs_iterate.restype = C.c_int
+    L.pmdi_gibbs_iterate.argtypes = [vp, i64, vp, vp]
+    L.pmdi_gibbs_step.restype = C.c_int
+    L.pmdi_gibbs_step.argtypes = [vp, i32, vp]
+    L.pmdi_gibbs_iterations.restype = i64
+    L.pmdi_gibbs_iterations.argtypes = [vp]
+    L.pmdi_gibbs_get.restype = C.c_int
+    L.pmdi_gibbs_get.argtypes = [vp, i32] + [vp] * 8
+    L.pmdi_gibbs_set.restype = C.c_int
+    L.pmdi_gibbs_set.argtypes = [vp, i32] + [vp] * 8
+    L.pmdi_gibbs_results.restype = C.c_int
+    L.pmdi_gibbs_results.argtypes = [vp, vp, vp, vp, vp]
+    L.pmdi_gibbs_device_view.restype = C.c_int
+    L.pmdi_gibbs_device_view.argtypes = [vp, vp]
     _lib = L
     return L
 
@@ -275,6 +315,84 @@ class Sweeper:
 
     def clusters(self, k, B):
         return ClusterBatch(self, k, B)
+
+
+class GibbsView(C.Structure):
+    _fields_ = [(f, C.c_void_p) for f in ("M", "gamma", "gamma0", "Phi", "vZ", "Pi", "log1p_phi", "feature_prob", "logweight",
+                                          "s", "order_obs", "p_star", "err", "stats", "feature_flag")] + [("n1", C.c_int64)]
+
+
+STEP_BEGIN, STEP_HYPERS, STEP_SWEEP, STEP_FEATSEL, STEP_ALIGN = range(5)
+
+
+class Gibbs:
+    """Device-resident Gibbs chains of a Sweeper's handle (include/pmdi_hip.h, pmdi_gibbs_*): M, gamma, Phi, v, Z,
+    the allocations and order_obs of every chain live on the MI355X; an iteration (src/pmdi.jl:164-384) is a
+    handful of kernel launches and nothing crosses PCIe."""
+
+    def __init__(self, sweeper, rho=0.25, feature_select=False):
+        self.sw = sweeper
+        h = C.c_void_p()
+        _check(lib().pmdi_gibbs_create(sweeper.h, float(rho), int(bool(feature_select)), C.byref(h)))
+        self.h = h
+        self.n1 = int(np.floor(rho * sweeper.n))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pmdi_gibbs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def iterate(self, n_iter=1, samples_ptr=None, stream=None):
+        _check(lib().pmdi_gibbs_iterate(self.h, int(n_iter), C.c_void_p(samples_ptr) if samples_ptr else None,
+                                        C.c_void_p(stream) if stream else None))
+
+    def step(self, what, stream=None):
+        _check(lib().pmdi_gibbs_step(self.h, int(what), C.c_void_p(stream) if stream else None))
+
+    @property
+    def iterations(self):
+        return int(lib().pmdi_gibbs_iterations(self.h))
+
+    def get(self, chain=0):
+        sw = self.sw
+        K, N, n = sw.K, sw.N, sw.n
+        M = np.zeros(K); gam = np.zeros((K, N)); gam0 = np.zeros((K, N)); Phi = np.zeros(sw.npairs); vZ = np.zeros(2)
+        s = np.zeros((K, n), dtype=np.int64); order = np.zeros(n, dtype=np.int64); fl = np.zeros(sw.sumD, dtype=np.uint8)
+        _check(lib().pmdi_gibbs_get(self.h, int(chain), _ptr(M), _ptr(gam), _ptr(gam0), _ptr(Phi), _ptr(vZ), _ptr(s), _ptr(order), _ptr(fl)))
+        return {"M": M, "gamma": gam.T.copy(), "gamma0": gam0.T.copy(), "Phi": Phi, "v": vZ[0], "Z": vZ[1],
+                "s": s.T.copy(), "order": order, "flags": fl}
+
+    def set(self, chain=0, M=None, gamma=None, gamma0=None, Phi=None, v=None, Z=None, s=None, order=None, flags=None):
+        """gamma, gamma0: (N, K); s: (n, K) labels 1..N; order: (n,) 1-based."""
+        f64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+        vZ = None
+        if v is not None or Z is not None:
+            cur = self.get(chain)
+            vZ = np.array([cur["v"] if v is None else v, cur["Z"] if Z is None else Z], dtype=np.float64)
+        g = None if gamma is None else np.ascontiguousarray(np.asarray(gamma, dtype=np.float64).T)
+        g0 = None if gamma0 is None else np.ascontiguousarray(np.asarray(gamma0, dtype=np.float64).T)
+        s_ = None if s is None else np.ascontiguousarray(np.asarray(s, dtype=np.int64).T)
+        o_ = None if order is None else np.ascontiguousarray(order, dtype=np.int64)
+        fl = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+        _check(lib().pmdi_gibbs_set(self.h, int(chain), _ptr(f64(M)), _ptr(g), _ptr(g0), _ptr(f64(Phi)), _ptr(vZ), _ptr(s_), _ptr(o_), _ptr(fl)))
+
+    def results(self):
+        sw = self.sw
+        stats = np.zeros((sw.C, 8), dtype=np.int64); err = np.zeros(sw.C, dtype=np.int32)
+        ps = np.zeros(sw.C, dtype=np.int64); lw = np.zeros((sw.C, sw.P))
+        _check(lib().pmdi_gibbs_results(self.h, _ptr(stats), _ptr(err), _ptr(ps), _ptr(lw)))
+        return {"stats": stats, "p_star": ps, "logweight": lw}
+
+    def view(self):
+        v = GibbsView()
+        _check(lib().pmdi_gibbs_device_view(self.h, C.addressof(v)))
+        return v
 
 
 class ClusterBatch:

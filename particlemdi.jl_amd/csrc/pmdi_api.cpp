@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #ifndef M_PI
@@ -41,6 +42,22 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// the device generator (pmdi_device.h uniform01) on the host: Philox4x32-10, ctr = (p, pos, site<<16|k, iter)
+double host_uniform01(unsigned long long seed, unsigned iter, unsigned pos, unsigned k, unsigned p, unsigned site)
+{
+    unsigned c0 = p, c1 = pos, c2 = (site << 16) | k, c3 = iter;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long m0 = (unsigned long long)0xD2511F53u * c0, m1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned hi0 = (unsigned)(m0 >> 32), lo0 = (unsigned)m0, hi1 = (unsigned)(m1 >> 32), lo1 = (unsigned)m1;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned long long m = ((unsigned long long)(c0 >> 6) << 26) | (unsigned long long)(c1 >> 6);
+    return (double)(2 * m + 1) * (1.0 / 9007199254740992.0);
+}
 
 struct DevBuf {
     void *p = nullptr;
@@ -129,6 +146,23 @@ struct pmdi_cluster_batch {
     DsetDev d{};
     void *arena = nullptr;
     DevBuf d_rows, d_flags, d_out;
+};
+
+// Device-resident Gibbs state of every chain of a handle (pmdi_gibbs_* entry points)
+struct pmdi_gibbs {
+    pmdi_handle *h = nullptr;
+    GibbsArgs ga{};
+    int *s_next = nullptr;               // the sweep's output; exchanged with ga.s after every sweep
+    unsigned char *flags = nullptr;      // [chain][sumD] featureFlag
+    double *fprob = nullptr;             // [chain][sumD] featureProb of the last feature selection
+    double *lw = nullptr;                // [chain][P]
+    int *pstar = nullptr;                // [chain]
+    long long *stats = nullptr;          // [chain][8]
+    int *err = nullptr;                  // [chain]
+    long long n1 = 0;
+    int feature_select = 0;
+    int64_t iter = 0;                    // Gibbs iterations done
+    std::vector<void *> owned;
 };
 
 namespace {
@@ -813,6 +847,265 @@ int pmdi_cluster_stats(pmdi_cluster_batch *cb, double *out, int64_t *stride)
             for (int q = 0; q < D; ++q) o[1 + q] = (double)s[(size_t)(b + 1) * D + q];
         }
     }
+    return PMDI_OK;
+}
+
+}  // extern "C"
+
+// ---- device-resident Gibbs chains ---------------------------------------------------------------
+namespace {
+template <class Tp>
+int galloc(pmdi_gibbs *g, Tp **p, size_t count)
+{
+    void *q = nullptr;
+    size_t bytes = count * sizeof(Tp);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) { *p = nullptr; return fail(PMDI_E_MEMORY, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    g->owned.push_back(q);
+    *p = (Tp *)q;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int pmdi_gibbs_destroy(pmdi_gibbs *g)
+{
+    if (!g) return PMDI_OK;
+    (void)hipSetDevice(g->h->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void *p : g->owned) (void)hipFree(p);
+    delete g;
+    return PMDI_OK;
+}
+
+int pmdi_gibbs_create(pmdi_handle *h, double rho, int32_t feature_select, pmdi_gibbs **out)
+{
+    if (!h || !out) return fail(PMDI_E_ARG, "null argument");
+    *out = nullptr;
+    if (!(rho < 1.0 && rho > 0.0)) return fail(PMDI_E_ARG, "rho must be between 0 and 1");          // src/pmdi.jl:53
+    const int K = h->cfg.K, N = h->cfg.N, P = h->cfg.P, C = h->cfg.n_chains;
+    const long long n = h->cfg.n;
+    const long long n1 = (long long)floor(rho * (double)n);                                           // :161
+    if (n1 < 1) return fail(PMDI_E_ARG, "floor(rho*n) = %lld < 1 (the reference indexes order_obs[0], SURVEY Q8)", n1);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    pmdi_gibbs *g = new (std::nothrow) pmdi_gibbs();
+    if (!g) return fail(PMDI_E_MEMORY, "out of host memory");
+    g->h = h; g->n1 = n1; g->feature_select = feature_select ? 1 : 0;
+    GibbsArgs &a = g->ga;
+    a.K = K; a.N = N; a.npairs = h->npairs; a.n_chains = C; a.n = n; a.iter = 0; a.seed = h->cfg.seed;
+    int rc = 0;
+    double *lg = nullptr;
+    const size_t tabsz = (size_t)K * K * N * N;
+    if ((rc = galloc(g, &a.M, (size_t)C * K)) || (rc = galloc(g, &a.gamma, (size_t)C * K * N)) ||
+        (rc = galloc(g, &a.gamma0, (size_t)C * K * N)) || (rc = galloc(g, &a.Phi, (size_t)C * h->npairs)) ||
+        (rc = galloc(g, &a.vZ, (size_t)C * 2)) || (rc = galloc(g, &a.s, (size_t)C * K * n)) ||
+        (rc = galloc(g, &g->s_next, (size_t)C * K * n)) || (rc = galloc(g, &a.order, (size_t)C * n)) ||
+        (rc = galloc(g, &a.Pi, (size_t)C * K * N)) || (rc = galloc(g, &a.logphi, (size_t)C * h->npairs)) ||
+        (rc = galloc(g, &a.wscr, (size_t)C * (n + 1))) || (rc = galloc(g, &lg, (size_t)n + 3)) ||
+        (rc = galloc(g, &g->flags, (size_t)C * h->sumD)) || (rc = galloc(g, &g->fprob, (size_t)C * h->sumD)) ||
+        (rc = galloc(g, &g->lw, (size_t)C * P)) || (rc = galloc(g, &g->pstar, (size_t)C)) ||
+        (rc = galloc(g, &g->stats, (size_t)C * 8)) || (rc = galloc(g, &g->err, (size_t)C))) {
+        pmdi_gibbs_destroy(g);
+        return rc;
+    }
+    a.ctab_lds = (tabsz * 4 <= 96 * 1024) ? 1 : 0;
+    a.order_lds = ((size_t)n * 4 <= 96 * 1024) ? 1 : 0;
+    a.ctab = nullptr;
+    if (!a.ctab_lds && K > 1 && (rc = galloc(g, &a.ctab, (size_t)C * tabsz))) { pmdi_gibbs_destroy(g); return rc; }
+    {
+        std::vector<double> t((size_t)n + 3);
+        for (size_t m = 0; m < t.size(); ++m) t[m] = lgamma((double)m);          // t[0] = inf is never read
+        if (hipMemcpy(lg, t.data(), t.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { pmdi_gibbs_destroy(g); return fail(PMDI_E_DEVICE, "memcpy failed"); }
+        a.lgtab = lg;
+    }
+    // featureFlag (src/pmdi.jl:106-110): rand(Bool) per feature when feature selection is on, else all true
+    {
+        std::vector<unsigned char> fl((size_t)C * h->sumD, 1);
+        if (g->feature_select)
+            for (int c = 0; c < C; ++c)
+                for (int k = 0; k < K; ++k)
+                    for (int q = 0; q < h->ds[k].D; ++q)
+                        fl[(size_t)c * h->sumD + h->ds[k].flag_off + q] =
+                            host_uniform01(h->cfg.seed + (unsigned long long)c, 0, 0, (unsigned)k, (unsigned)q, SITE_INIT_FLAGS) < 0.5 ? 1 : 0;
+        if (hipMemcpy(g->flags, fl.data(), fl.size(), hipMemcpyHostToDevice) != hipSuccess) { pmdi_gibbs_destroy(g); return fail(PMDI_E_DEVICE, "memcpy failed"); }
+    }
+    if (hipMemset(g->err, 0, (size_t)C * 4) != hipSuccess || hipMemset(g->stats, 0, (size_t)C * 64) != hipSuccess) {
+        pmdi_gibbs_destroy(g);
+        return fail(PMDI_E_DEVICE, "memset failed");
+    }
+    hipError_t e = pmdi_launch_gibbs_init(a, h->stream);
+    if (e != hipSuccess) { pmdi_gibbs_destroy(g); return fail(PMDI_E_DEVICE, "gibbs init launch: %s", hipGetErrorString(e)); }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { pmdi_gibbs_destroy(g); return fail(PMDI_E_DEVICE, "gibbs init kernel failed"); }
+    *out = g;
+    return PMDI_OK;
+}
+
+int pmdi_gibbs_step(pmdi_gibbs *g, int32_t what, void *stream)
+{
+    if (!g) return fail(PMDI_E_ARG, "null argument");
+    pmdi_handle *h = g->h;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    GibbsArgs a = g->ga;
+    hipError_t e;
+    switch (what) {
+    case PMDI_STEP_BEGIN:
+        g->iter += 1;
+        return PMDI_OK;
+    case PMDI_STEP_HYPERS:
+        a.iter = (unsigned)g->iter;
+        e = pmdi_launch_hypers(a, 1, st);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "hypers launch: %s", hipGetErrorString(e));
+        return PMDI_OK;
+    case PMDI_STEP_SWEEP: {
+        const int rc = pmdi_sweep_device(h, g->iter, a.s, a.order, g->n1, a.Pi, a.logphi, g->flags, g->iter == 1 ? 0.0 : 1.0,
+                                         g->s_next, g->lw, g->pstar, (int64_t *)g->stats, g->err, stream);
+        if (rc) return rc;
+        std::swap(g->ga.s, g->s_next);               // s = sstar[p_star, :, :] (src/pmdi.jl:373)
+        return PMDI_OK;
+    }
+    case PMDI_STEP_FEATSEL: {
+        FeatSelArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.K = h->cfg.K; fa.N = h->cfg.N; fa.sumD = h->sumD; fa.n = h->cfg.n; fa.iter = (unsigned)g->iter; fa.seed = h->cfg.seed;
+        for (int k = 0; k < h->cfg.K; ++k) fa.ds[k] = h->ds[k];
+        fa.traj = a.s; fa.lm = (double *)h->d_lm.p; fa.firstpos = (int *)h->d_firstpos.p;
+        fa.fnull = (const double *)h->d_fnull.p; fa.flags_out = g->flags; fa.prob_out = g->fprob;
+        e = pmdi_launch_featsel(fa, h->cfg.n_chains, st);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "feature-select launch: %s", hipGetErrorString(e));
+        return PMDI_OK;
+    }
+    case PMDI_STEP_ALIGN:
+        a.iter = (unsigned)g->iter;
+        e = pmdi_launch_align(a, st);
+        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "align launch: %s", hipGetErrorString(e));
+        return PMDI_OK;
+    default:
+        return fail(PMDI_E_ARG, "unknown step %d", what);
+    }
+}
+
+int pmdi_gibbs_iterate(pmdi_gibbs *g, int64_t n_iter, uint8_t *samples, void *stream)
+{
+    if (!g || n_iter < 0) return fail(PMDI_E_ARG, "bad argument");
+    const pmdi_handle *h = g->h;
+    const long long per = (long long)h->cfg.n_chains * h->cfg.K * h->cfg.n;
+    for (int64_t t = 0; t < n_iter; ++t) {
+        int rc;
+        if ((rc = pmdi_gibbs_step(g, PMDI_STEP_BEGIN, stream)) || (rc = pmdi_gibbs_step(g, PMDI_STEP_HYPERS, stream)) ||
+            (rc = pmdi_gibbs_step(g, PMDI_STEP_SWEEP, stream)))
+            return rc;
+        if (g->feature_select && (rc = pmdi_gibbs_step(g, PMDI_STEP_FEATSEL, stream))) return rc;
+        if ((rc = pmdi_gibbs_step(g, PMDI_STEP_ALIGN, stream))) return rc;
+        if (samples) {
+            hipError_t e = pmdi_launch_pack_samples(g->ga.s, samples + (size_t)t * per, per, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(PMDI_E_DEVICE, "pack-samples launch: %s", hipGetErrorString(e));
+        }
+    }
+    return PMDI_OK;
+}
+
+int64_t pmdi_gibbs_iterations(const pmdi_gibbs *g) { return g ? g->iter : 0; }
+
+int pmdi_gibbs_device_view(pmdi_gibbs *g, pmdi_gibbs_view *v)
+{
+    if (!g || !v) return fail(PMDI_E_ARG, "null argument");
+    v->M = g->ga.M; v->gamma = g->ga.gamma; v->gamma0 = g->ga.gamma0; v->Phi = g->ga.Phi; v->vZ = g->ga.vZ;
+    v->s = g->ga.s; v->order_obs = g->ga.order; v->Pi = g->ga.Pi; v->log1p_phi = g->ga.logphi;
+    v->feature_flag = g->flags; v->feature_prob = g->fprob; v->logweight = g->lw; v->p_star = g->pstar;
+    v->stats = (int64_t *)g->stats; v->err = g->err; v->n1 = g->n1;
+    return PMDI_OK;
+}
+
+int pmdi_gibbs_get(pmdi_gibbs *g, int32_t chain, double *M, double *gamma, double *gamma0, double *Phi, double *vZ,
+                   int64_t *s, int64_t *order_obs, uint8_t *feature_flag)
+{
+    if (!g) return fail(PMDI_E_ARG, "null argument");
+    const pmdi_handle *h = g->h;
+    const int K = h->cfg.K, N = h->cfg.N;
+    const long long n = h->cfg.n;
+    if (chain < 0 || chain >= h->cfg.n_chains) return fail(PMDI_E_ARG, "chain out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const GibbsArgs &a = g->ga;
+    if (M) HIP_TRY(hipMemcpy(M, a.M + (size_t)chain * K, (size_t)K * 8, hipMemcpyDeviceToHost));
+    if (gamma) HIP_TRY(hipMemcpy(gamma, a.gamma + (size_t)chain * K * N, (size_t)K * N * 8, hipMemcpyDeviceToHost));    // N x K column-major
+    if (gamma0) HIP_TRY(hipMemcpy(gamma0, a.gamma0 + (size_t)chain * K * N, (size_t)K * N * 8, hipMemcpyDeviceToHost));
+    if (Phi) HIP_TRY(hipMemcpy(Phi, a.Phi + (size_t)chain * h->npairs, (size_t)h->npairs * 8, hipMemcpyDeviceToHost));
+    if (vZ) HIP_TRY(hipMemcpy(vZ, a.vZ + (size_t)chain * 2, 16, hipMemcpyDeviceToHost));
+    if (s) {
+        std::vector<int> t((size_t)K * n);
+        HIP_TRY(hipMemcpy(t.data(), a.s + (size_t)chain * K * n, t.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < t.size(); ++i) s[i] = (int64_t)t[i] + 1;         // n x K column-major, labels 1..N
+    }
+    if (order_obs) {
+        std::vector<int> t((size_t)n);
+        HIP_TRY(hipMemcpy(t.data(), a.order + (size_t)chain * n, t.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < t.size(); ++i) order_obs[i] = (int64_t)t[i] + 1;
+    }
+    if (feature_flag) HIP_TRY(hipMemcpy(feature_flag, g->flags + (size_t)chain * h->sumD, (size_t)h->sumD, hipMemcpyDeviceToHost));
+    return PMDI_OK;
+}
+
+int pmdi_gibbs_set(pmdi_gibbs *g, int32_t chain, const double *M, const double *gamma, const double *gamma0, const double *Phi,
+                   const double *vZ, const int64_t *s, const int64_t *order_obs, const uint8_t *feature_flag)
+{
+    if (!g) return fail(PMDI_E_ARG, "null argument");
+    const pmdi_handle *h = g->h;
+    const int K = h->cfg.K, N = h->cfg.N;
+    const long long n = h->cfg.n;
+    if (chain < 0 || chain >= h->cfg.n_chains) return fail(PMDI_E_ARG, "chain out of range");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const GibbsArgs &a = g->ga;
+    if (M) HIP_TRY(hipMemcpy(a.M + (size_t)chain * K, M, (size_t)K * 8, hipMemcpyHostToDevice));
+    if (gamma) HIP_TRY(hipMemcpy(a.gamma + (size_t)chain * K * N, gamma, (size_t)K * N * 8, hipMemcpyHostToDevice));
+    if (gamma0) HIP_TRY(hipMemcpy(a.gamma0 + (size_t)chain * K * N, gamma0, (size_t)K * N * 8, hipMemcpyHostToDevice));
+    if (Phi) HIP_TRY(hipMemcpy(a.Phi + (size_t)chain * h->npairs, Phi, (size_t)h->npairs * 8, hipMemcpyHostToDevice));
+    if (vZ) HIP_TRY(hipMemcpy(a.vZ + (size_t)chain * 2, vZ, 16, hipMemcpyHostToDevice));
+    if (s) {
+        std::vector<int> t((size_t)K * n);
+        for (size_t i = 0; i < t.size(); ++i) {
+            if (s[i] < 1 || s[i] > N) return fail(PMDI_E_DATA, "s[%zu]=%lld outside 1..N", i, (long long)s[i]);
+            t[i] = (int)(s[i] - 1);
+        }
+        HIP_TRY(hipMemcpy(a.s + (size_t)chain * K * n, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (order_obs) {
+        std::vector<int> t((size_t)n);
+        for (size_t i = 0; i < t.size(); ++i) {
+            if (order_obs[i] < 1 || order_obs[i] > n) return fail(PMDI_E_DATA, "order_obs[%zu]=%lld outside 1..n", i, (long long)order_obs[i]);
+            t[i] = (int)(order_obs[i] - 1);
+        }
+        HIP_TRY(hipMemcpy(a.order + (size_t)chain * n, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (feature_flag) HIP_TRY(hipMemcpy(g->flags + (size_t)chain * h->sumD, feature_flag, (size_t)h->sumD, hipMemcpyHostToDevice));
+    return PMDI_OK;
+}
+
+int pmdi_gibbs_results(pmdi_gibbs *g, int64_t *stats, int32_t *err, int64_t *p_star, double *logweight)
+{
+    if (!g) return fail(PMDI_E_ARG, "null argument");
+    const pmdi_handle *h = g->h;
+    const int C = h->cfg.n_chains;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (stats) HIP_TRY(hipMemcpy(stats, g->stats, (size_t)C * 64, hipMemcpyDeviceToHost));
+    std::vector<int> er(C);
+    HIP_TRY(hipMemcpy(er.data(), g->err, (size_t)C * 4, hipMemcpyDeviceToHost));
+    if (err) memcpy(err, er.data(), (size_t)C * 4);
+    if (p_star) {
+        std::vector<int> ps(C);
+        HIP_TRY(hipMemcpy(ps.data(), g->pstar, (size_t)C * 4, hipMemcpyDeviceToHost));
+        for (int c = 0; c < C; ++c) p_star[c] = (int64_t)ps[c] + 1;
+    }
+    if (logweight) HIP_TRY(hipMemcpy(logweight, g->lw, (size_t)C * h->cfg.P * 8, hipMemcpyDeviceToHost));
+    for (int c = 0; c < C; ++c)
+        if (er[c] != 0)
+            return fail(er[c] == PMDI_E_POOL ? PMDI_E_POOL : PMDI_E_STATE,
+                        er[c] == PMDI_E_POOL ? "chain %d: cluster pool capacity %lld exceeded" : "chain %d: kernel reported error", c, h->cap);
     return PMDI_OK;
 }
 

@@ -17,7 +17,10 @@
 #define PMDI_DL_LDS 128     // distinct-chosen-cluster entries kept in LDS (fallback path)
 
 enum { K_GAUSSIAN = 0, K_CATEGORICAL = 1, K_NEGBINOM = 2 };
-enum { SITE_DRAW = 0, SITE_RESAMPLE_U = 1, SITE_RESAMPLE_SLOT = 2, SITE_PSTAR = 3, SITE_FEATSEL = 4 };
+enum { SITE_DRAW = 0, SITE_RESAMPLE_U = 1, SITE_RESAMPLE_SLOT = 2, SITE_PSTAR = 3, SITE_FEATSEL = 4,
+       // the per-iteration work around the sweep (pmdi_hypers.hip; same numbering as oracle/pmdi_oracle_hypers.c)
+       SITE_SHUFFLE = 5, SITE_M_NORMAL = 6, SITE_M_ACCEPT = 7, SITE_GAMMA = 8, SITE_PHI_ALPHA = 9, SITE_PHI_GAMMA = 10,
+       SITE_V = 11, SITE_ALIGN = 12, SITE_INIT_GAMMA = 13, SITE_INIT_PHI = 14, SITE_INIT_S = 15, SITE_INIT_FLAGS = 16 };
 enum { ST_NOPS = 0, ST_NRESAMPLE = 1, ST_NCLONES = 2, ST_MAXID = 3, ST_SUMCLASSES = 4 };
 
 // One dataset as the kernels see it.  Data are row-major on the device so
@@ -116,6 +119,36 @@ struct FeatSelArgs {
     unsigned char *flags_out; // [chain][sumD]
     double *prob_out;         // [chain][sumD]
 };
+
+// Device-resident Gibbs state of every chain of a handle (src/pmdi.jl:59-96) and the scratch of the
+// hyper-parameter / label-alignment kernels (pmdi_hypers.hip).
+struct GibbsArgs {
+    int K, N, npairs, n_chains;
+    long long n;
+    unsigned iter;
+    unsigned long long seed;
+    double *M;          // [chain][K]
+    double *gamma;      // [chain][K][N]   gamma_c
+    double *gamma0;     // [chain][K][N]   the initial gamma_c: exp(Gamma_c), never refreshed
+    double *Phi;        // [chain][npairs]
+    double *vZ;         // [chain][2]      (v, Z)
+    int *s;             // [chain][K][n]   allocations, 0-based labels
+    int *order;         // [chain][n]      order_obs, 0-based
+    double *Pi;         // [chain][K][N]   gamma ./ sum(gamma)  (src/pmdi.jl:179)
+    double *logphi;     // [chain][npairs] log(1 + Phi)         (src/misc.jl:53)
+    int *ctab;          // [chain][K][K][N][N] contingency tables of align_labels (diagonal blocks unused)
+    double *wscr;       // [chain][n + 1]  weights of the alpha* draw in update_Phi!
+    const double *lgtab;// [n + 3]         lgamma(m), host-built (same libm as the oracle)
+    int ctab_lds;       // 1: the contingency tables fit LDS
+    int order_lds;      // 1: order_obs fits LDS during the shuffle
+};
+
+size_t pmdi_hypers_lds_bytes(const GibbsArgs &a);
+size_t pmdi_align_lds_bytes(const GibbsArgs &a);
+hipError_t pmdi_launch_gibbs_init(const GibbsArgs &a, hipStream_t stream);
+hipError_t pmdi_launch_hypers(const GibbsArgs &a, int do_shuffle, hipStream_t stream);
+hipError_t pmdi_launch_align(const GibbsArgs &a, hipStream_t stream);
+hipError_t pmdi_launch_pack_samples(const int *s, unsigned char *out, long long count, hipStream_t stream);
 
 size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T);
 hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t stream);
