@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- Gibbs iterations/sec of the conditional-SMC sweep on MI355X.
+"""bench.py -- Gibbs iterations/sec of ParticleMDI's conditional-SMC sweep on MI355X.
 
-One "step" = one Gibbs iteration of every chain on this rank: shuffle, host hyper-updates
-(M, gamma, Pi), then the whole sweep (src/pmdi.jl:165-171, 188-350, 373) as ONE persistent HIP
-kernel launch that advances all `chains` chains (one workgroup per chain).  Workload at N=1:
-BASELINE.json configs[1] ("cfg2": synthetic 3-mixture Gaussian 10k x 50, K=1, N=20, 1024
-particles, rho=0.25).  `value` is the whole-job aggregate over all chains and ranks.
+Workload at N=1 (default): the north-star headline "HL" -- 4 Gaussian datasets of 10 000 x 50 sharing a 3-cluster
+structure, K = 4, N = 20 clusters, 1 024 particles, rho = 0.25 (BASELINE.json north_star; D and N are SURVEY 8d's
+stated assumptions).  `--workload cfg2|cfg3|cfg4|cfg5` runs the other BASELINE configs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--chains C] [--scale S] [--no-cpu]
+One "step" = one Gibbs iteration (src/pmdi.jl:164-384) of every chain on this rank, entirely on the device through
+the C ABI (pmdi_gibbs_step): shuffle + hyper-parameter updates (one kernel), the whole conditional-SMC sweep (one
+persistent kernel per launch group, one workgroup per chain), feature selection when the config has it, label
+alignment (one kernel).  Inputs are resident: nothing crosses PCIe inside the timed region.
 
-For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU;
-chains are independent (no data-path collective) and the retained allocation samples are
-all-gathered over RCCL at the end for the posterior-similarity matrix (scaling: weak).
+Protocol (state-independent by construction -- the cost of a sweep depends on how settled the chains are):
+  1. `--burnin B` iterations from the random start of src/pmdi.jl:59-66, timed separately (`burnin_iters_per_sec`:
+     what a user sees for the first B iterations);  B is a property of the workload, NOT of --warmup;
+  2. `--warmup W` untimed iterations;  3. exactly `--steps K` timed iterations -> `value` (settled chains).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload HL] [--chains C] [--burnin B] [--no-cpu]
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank per GPU; chains are independent (no
+data-path collective, scaling: weak) and the retained allocation samples of the timed iterations are all-gathered
+over RCCL at the end for the posterior-similarity matrix.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,67 +37,125 @@ import __graft_entry__ as G  # noqa: E402
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW"
 
+DESCR = {
+    "HL": "HL (north-star headline): 4 x Gaussian 10000x50, K=4, N=20, P=1024, rho=0.25",
+    "cfg2": "cfg2: 3-mixture Gaussian 10000x50, K=1, N=20, P=1024, rho=0.25",
+    "cfg3": "cfg3: Gaussian 5000x50 + Categorical 5000x20, K=2, N=30, P=1024, rho=0.25",
+    "cfg4": "cfg4: 2 x Gaussian 10000x50 + Categorical 10000x20 + NegBinom 10000x30, K=4, N=50, P=2048, rho=0.25",
+    "cfg5": "cfg5: 3 x Gaussian 20000x200, K=3, N=50, P=4096, rho=0.25, featureSelect on",
+}
+# chains per GPU (one workgroup each) and burn-in iterations per workload
+DEFAULTS = {"HL": (512, 12), "cfg2": (2048, 30), "cfg3": (512, 12), "cfg4": (256, 6), "cfg5": (256, 3)}
 
-def cpu_baseline(w, warm, timed, seed=5):
-    """The oracle (a single-threaded port of the reference's loop, reference-cost bookkeeping
-    kept) timed on this box's host cores for the same workload, one chain, 1 core."""
+
+def algorithmic_bytes(w, P, n, n1, work, stats):
+    """De-duplication-aware algorithmic HBM bytes of one sweep of every chain, from the kernel's own work counters
+    (pmdi_work_counters; DESIGN.md section 6 has the derivation).  work: (C, K, 8); stats: (C, 8)."""
+    N, K = w["N"], w["K"]
+    n_s = n - n1 + 1
+    C = work.shape[0]
+    tot = 0.0
+    for k, (kind, D) in enumerate(zip(w["kinds"], w["D"])):
+        ev, up, cl, moved, mev = (work[:, k, j].astype(np.float64).sum() for j in range(5))
+        if kind == "gaussian":                   # pool entry = (Sigma, beta) per feature (16 B) + n (4 B)
+            b_eval, b_upd, b_clone_extra, b_x = 16 * D + 4, 2 * 16 * D + 8, 0, 8 * D
+        elif kind == "categorical":              # one count per feature at the observed level; a clone copies L levels
+            L = int(w["data"][k].max())
+            b_eval, b_upd, b_clone_extra, b_x = 4 * D + 4, 2 * 4 * D + 8, 2 * 4 * D * (L - 1), 4 * D
+        else:                                    # NegBinom: Sigma per feature (8 B)
+            b_eval, b_upd, b_clone_extra, b_x = 8 * D + 4, 2 * 8 * D + 8, 0, 4 * D
+        per_step = b_x + P * (4 + 1)                                   # obs row; label->cluster read + sstar byte per particle
+        prefix = (n1 - 1) * (b_x + 8) + N * P * 4 * 2                  # known-prefix rows + s_in/order; particle / new_id reset
+        final = n * 4 + n_s * 1                                        # s_out write, sstar[p_star] reads
+        resample = stats[:, 1].astype(np.float64).sum() * (3 * N * P * 4 + P * 4)   # gather r+w, relabel read, class ids
+        tot += ev * b_eval + up * b_upd + cl * b_clone_extra + moved * (b_upd - 8) + mev * N * P * 4 \
+            + resample + C * (n_s * per_step + prefix + final)
+    return tot
+
+
+def oracle_chain(w, state, n_iter, seed, progress=False):
+    """The CPU path beside it: the oracle (single-threaded restatement of src/pmdi.jl + update_hypers.jl + align_labels!,
+    reference-cost bookkeeping kept) continuing one chain from `state` (a settled chain of the GPU run).
+    Returns the seconds of every iteration: (whole iteration, sweep only)."""
     O = G.load_oracle()
-    from particlemdi_jl_amd.hypers import HyperState
-    n, N, P = w["n"], w["N"], w["P"]
-    rng = np.random.default_rng(seed - 4)
-    hy = HyperState(n, N, 1, rng)
+    n, N, K, P = w["n"], w["N"], w["K"], w["P"]
+    hy = O.Hypers(n, N, K, seed=seed)
+    hy.M, hy.gamma, hy.gamma0, hy.Phi = state["M"], state["gamma"], state["gamma0"], state["Phi"]
+    hy.v, hy.Z = float(state["v"]), float(state["Z"])
+    hy.s[:] = state["s"]
+    hy.order[:] = state["order"]
     orc = O.Oracle(w["data"], w["kinds"], N, P, seed=seed, faithful_cost=1)
-    order = np.arange(1, n + 1)
     n1 = int(np.floor(w["rho"] * n))
-    secs = []
-    for it in range(1, warm + timed + 1):
-        rng.shuffle(order)
-        Pi = hy.step_pmdi_order()
-        r = orc.sweep(it, hy.s, order, n1, Pi, hy.Phi)
+    flags = [np.ones(d, dtype=np.uint8) for d in w["D"]]
+    out = []
+    for it in range(1, n_iter + 1):
+        t0 = time.perf_counter()
+        Pi = hy.step(1000 + it)
+        r = orc.sweep(1000 + it, np.array(hy.s), np.array(hy.order), n1, Pi, hy.Phi, flags, lw_init=1.0)
+        if w["name"] == "cfg5":
+            flags, _ = orc.feature_select(1000 + it, r["s"])
         hy.s[:] = r["s"]
-        if it > warm:
-            secs.append(r["stats"]["seconds"])
-        if seed == 5:
-            print(f"[bench] cpu baseline iteration {it}/{warm + timed}: {r['stats']['seconds']:.2f} s", file=sys.stderr, flush=True)
-    orc.close()
-    return float(np.mean(secs)), secs
+        hy.align_labels(1000 + it)
+        out.append((time.perf_counter() - t0, r["stats"]["seconds"]))
+        if progress:
+            print(f"[bench] cpu baseline iteration {it}/{n_iter}: {out[-1][0]:.2f} s (sweep {out[-1][1]:.2f} s)", file=sys.stderr, flush=True)
+    orc.close(); hy.close()
+    return out
 
 
 def _cpu_worker(args):
-    scale, warm, timed, seed = args
+    name, scale, path, chain, n_iter, seed = args
     sys.path.insert(0, ROOT)
     G.load_package()
     from particlemdi_jl_amd import workloads
-    w = workloads.make("cfg2", scale)
-    sec, _ = cpu_baseline(w, warm, timed, seed)
-    return sec
+    w = workloads.make(name, scale)
+    z = np.load(path)
+    state = {k[len(f"c{chain}_"):]: z[k] for k in z.files if k.startswith(f"c{chain}_")}
+    return oracle_chain(w, state, n_iter, seed)
 
 
-def cpu_baseline_all_cores(scale, warm, timed):
-    """the all-cores figure -- one independent chain per host core, what a user of the
-    single-threaded reference could do with `julia -p`.  Returns (aggregate iters/s, cores)."""
+def cpu_baseline(w, scale, states, budget_s):
+    """One oracle chain per host core, all at once (what a user of the single-threaded reference can do with
+    `julia -p`), each continuing a different settled chain of the GPU run; the iteration count is sized from one
+    probe iteration so that the leg stays near `budget_s` seconds."""
     import multiprocessing as mp
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    with mp.get_context("spawn").Pool(cores) as pool:
-        secs = pool.map(_cpu_worker, [(scale, warm, timed, 5 + c) for c in range(cores)])
-    return float(sum(1.0 / x for x in secs)), cores
+    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    probe = oracle_chain(w, states[0], 1, 5, progress=True)[0]          # also: the 1-core figure with the box otherwise idle
+    n_iter = int(max(1, min(8, (budget_s - probe[0]) // max(probe[0] * 1.3, 1e-3))))
+    # one oracle pool is (N*P+1) cluster objects per dataset (src/pmdi.jl:140): bound the workers by host memory
+    pool_bytes = sum((w["N"] * w["P"] + 1) * d * (32 if kind == "gaussian" else 8 * (int(x.max()) if kind == "categorical" else 1))
+                     for kind, d, x in zip(w["kinds"], w["D"], w["data"]))
+    workers = int(max(1, min(host_cores, 24e9 // max(pool_bytes, 1))))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "states.npz")
+        np.savez(path, **{f"c{c}_{k}": v for c, st in enumerate(states) for k, v in st.items()})
+        with mp.get_context("spawn").Pool(workers) as pool:
+            res = pool.map(_cpu_worker, [(w["name"], scale, path, c % len(states), n_iter, 100 + c) for c in range(workers)])
+    per_core = [np.mean([x[0] for x in r]) for r in res]
+    sweep_frac = float(np.mean([x[1] / x[0] for r in res for x in r]))
+    return {"value": float(sum(1.0 / x for x in per_core)), "unit": "Gibbs iters/s (whole iterations, one chain per core, aggregate)",
+            "cores": workers, "host_cores": host_cores, "kind": "port",
+            "one_core_alone_iters_per_sec": 1.0 / probe[0], "per_core_iters_per_sec_all_busy": float(np.mean([1.0 / x for x in per_core])),
+            "sweep_fraction_of_iteration": sweep_frac,
+            "sample": f"oracle (C restatement of pmdi.jl sweep + update_hypers.jl + align_labels!, single-threaded like the reference), "
+                      f"same workload, {workers} chains at once (one per host core{'' if workers == host_cores else ', capped by host memory'}) x {n_iter} iteration(s), each continuing a settled "
+                      f"chain of the GPU run; 1 probe iteration alone first ({time.perf_counter() - t0:.0f} s of wall time in total)"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--chains", type=int, default=2048, help="independent chains per GPU (one workgroup each)")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="HL", choices=sorted(DESCR))
+    ap.add_argument("--chains", type=int, default=0, help="independent chains per GPU (one workgroup each); 0 = the workload's default")
+    ap.add_argument("--burnin", type=int, default=-1, help="iterations from the random start before --warmup; -1 = the workload's default")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n of the workload (debug only)")
     ap.add_argument("--block", type=int, default=0)
-    ap.add_argument("--groups", type=int, default=1,
-                    help="drive the chains of a GPU as this many independent groups, each on its own stream "
-                         "(measured: 2 groups 15%% slower, 4 groups 40%% slower than 1 -- a launch is bounded by its "
-                         "slowest chain and concurrent launches slow each other's slow chains down)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=30)
-    ap.add_argument("--cpu-all", action="store_true", help="also time one oracle chain per host core (SURVEY 8d all-cores figure; minutes)")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="wall-time budget of the CPU baseline leg")
+    ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,77 +166,84 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
 
     G.build()
     pkg = G.load_package()
     from particlemdi_jl_amd import workloads
-    from particlemdi_jl_amd.batched import DeviceGibbsK1
 
-    w = workloads.make("cfg2", args.scale)
-    n, N, P, C = w["n"], w["N"], w["P"], args.chains
-    NG = max(1, min(args.groups, C))
-    Cg = [C // NG + (1 if gi < C % NG else 0) for gi in range(NG)]
-    streams = [torch.cuda.Stream(device=local_rank) for _ in range(NG)]
-    groups = []
-    for gi in range(NG):
-        with torch.cuda.stream(streams[gi]):
-            groups.append(DeviceGibbsK1(w["data"][0], "gaussian", N, P, Cg[gi], seed=1000 + 7919 * rank + 104729 * gi,
-                                        device=local_rank, block_threads=args.block, rho=w["rho"]))
-    g = groups[0]
-    n_s = n - g.n1 + 1
+    w = workloads.make(args.workload, args.scale)
+    n, N, P, K = w["n"], w["N"], w["P"], w["K"]
+    C = args.chains or DEFAULTS[args.workload][0]
+    burnin = args.burnin if args.burnin >= 0 else DEFAULTS[args.workload][1]
+    # chain c of rank r draws from Philox key base + r * 2^32 + c: no two chains of a job share a stream
+    seed = 1000 + (rank << 32)
+    sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=C, seed=seed, device=local_rank, block_threads=args.block)
+    g = pkg.Gibbs(sw, rho=w["rho"], feature_select=(args.workload == "cfg5"))
+    n1 = g.n1
+    n_s = n - n1 + 1
+    stream = torch.cuda.current_stream(dev)
+    sp = stream.cuda_stream
 
-    def all_stats():
-        return np.concatenate([gr.check() for gr in groups], axis=0)
+    def iteration(events=None):
+        g.step(pkg.STEP_BEGIN, sp)
+        g.step(pkg.STEP_HYPERS, sp)
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        g.step(pkg.STEP_SWEEP, sp)
+        if events is not None:
+            e1.record(stream)
+            events.append((e0, e1))
+        if args.workload == "cfg5":
+            g.step(pkg.STEP_FEATSEL, sp)
+        g.step(pkg.STEP_ALIGN, sp)
 
-    for w_it in range(args.warmup):
-        for gi, gr in enumerate(groups):
-            with torch.cuda.stream(streams[gi]):
-                gr.iteration()
-        if os.environ.get("PMDI_BENCH_VERBOSE") and rank == 0:
-            st = all_stats()
-            print(f"warmup {w_it}: ids/step {st[:, 0].mean() / n_s:.1f} classes/step {st[:, 4].mean() / n_s:.2f} "
-                  f"resamples {st[:, 1].mean():.1f}", file=sys.stderr, flush=True)
-    all_stats()
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    samples = [torch.empty((args.steps, Cg[gi], n), dtype=torch.uint8, device=g.dev) for gi in range(NG)]
-    base = torch.cuda.Event(enable_timing=True)
+    # ---- 1. burn-in from the random start (timed on its own) ----
+    barrier()
+    tb = time.perf_counter()
+    for b in range(burnin):
+        ev = []
+        iteration(ev)
+        if args.verbose and rank == 0:
+            torch.cuda.synchronize()
+            st = g.results()["stats"]
+            print(f"[bench] burn-in {b + 1}: sweep {ev[0][0].elapsed_time(ev[0][1]):8.1f} ms  ids/step {st[:, 0].mean() / (n_s * K):7.1f} "
+                  f"classes/step {st[:, 4].mean() / (n_s * K):6.2f} resamples {st[:, 1].mean():7.1f}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    base.record(torch.cuda.current_stream())
-    torch.cuda.synchronize()
+    burnin_s = time.perf_counter() - tb
+    g.results()          # raises if a chain reported an error
+    # ---- 2. warm-up ----
+    for _ in range(args.warmup):
+        iteration()
+    # ---- 3. the timed region: exactly --steps iterations ----
+    samples = torch.empty((args.steps, C, K, n), dtype=torch.uint8, device=dev)
+    per = C * K * n
+    events = []
+    barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        for gi, gr in enumerate(groups):
-            with torch.cuda.stream(streams[gi]):
-                gr.iteration(time_kernel=True)          # waits for this group's previous sweep only
-                samples[gi][k].copy_(gr.s)              # retained allocation sample of this iteration
+        iteration(events)
+        g.pack_samples(samples.data_ptr() + k * per, sp)       # retained allocation sample of this iteration (uint8): the PSM's input
     torch.cuda.synchronize()
     if dist is not None:
-        allsamp = torch.cat(samples, dim=1)
-        gathered = torch.empty((world,) + tuple(allsamp.shape), dtype=torch.uint8, device=g.dev)
-        dist.all_gather_into_tensor(gathered, allsamp)      # RCCL over xGMI: PSM input
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+        gathered = torch.empty((world,) + tuple(samples.shape), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, samples)      # RCCL over xGMI: PSM input
+    barrier()
     dt = time.perf_counter() - t0
-    stats = all_stats()
-    # per-launch durations and the time at least one sweep launch was running (HIP events on the launch streams)
-    ivals = sorted((base.elapsed_time(e0), base.elapsed_time(e1)) for gr in groups for (e0, e1) in gr.events)
-    launch_ms = [b - a for a, b in ivals]
-    busy_ms, cur_a, cur_b = 0.0, None, None
-    for a, b in ivals:
-        if cur_b is None or a > cur_b:
-            if cur_b is not None:
-                busy_ms += cur_b - cur_a
-            cur_a, cur_b = a, b
-        else:
-            cur_b = max(cur_b, b)
-    busy_ms += (cur_b - cur_a) if cur_b is not None else 0.0
+    res = g.results()
+    stats = res["stats"]
+    work = sw.work_counters()
+    costs = sw.chain_costs().astype(np.float64)               # shader cycles of every chain's last sweep
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
-    t = torch.tensor([dt], dtype=torch.float64, device=g.dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -177,65 +251,63 @@ def main():
     out = None
     if rank == 0:
         total_iters = args.steps * C * world
-        kernel_ms = float(np.mean(launch_ms))                     # one launch = the chains of one group
-        bytes_unit = workloads.algorithmic_bytes_per_obs_particle(w["kinds"], w["D"], N)
-        alg_bytes_launch = float(bytes_unit) * n_s * P * (C / NG)
-        achieved = alg_bytes_launch / (kernel_ms * 1e-3)
+        clock_hz = float(sw.clock_hz)
+        chain_s = costs / clock_hz
+        alg = algorithmic_bytes(w, P, n, n1, work, stats)                       # bytes of the last timed sweep, all chains
+        dense = float(workloads.algorithmic_bytes_per_obs_particle(w["kinds"], w["D"], N)) * n_s * P * C
+        achieved = alg / (kernel_ms * 1e-3)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):       # PMC-measured HBM bytes per launch of this same command (profiles/README.md)
-            tj = json.load(open(tpath))
-            if tj.get("chains_per_gpu") == C and tj.get("groups", 1) == NG and tj.get("workload") == "cfg2" and args.scale == 1.0:
-                traffic = tj["hbm_bytes_per_launch"]
+        key = f"{args.workload}|chains={C}|burnin={burnin}|warmup={args.warmup}|steps={args.steps}|scale={args.scale}"
+        if os.path.exists(tpath):       # PMC-measured HBM bytes per sweep of this exact command line (profiles/README.md), else null
+            traffic = json.load(open(tpath)).get(key, {}).get("hbm_bytes_per_sweep")
         out = {
             "metric": "Gibbs iters/sec (and obs·particles/sec) at 1/2/4/8 GPUs vs CPU ref",
             "value": total_iters / dt,
-            "unit": "Gibbs iters/s (aggregate over chains)",
+            "unit": "Gibbs iters/s (aggregate over chains, settled chains)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg2: 3-mixture Gaussian 10000x50, K=1, N=20, P=1024, rho=0.25"
-                       if args.scale == 1.0 else f"cfg2 scaled n={n}",
-                       "chains_per_gpu": C, "chain_groups": NG, "chains_per_launch": C // NG,
-                       "block_threads": g.sw.block_threads, "lds_bytes_per_chain": g.sw.lds_bytes,
-                       "swept_obs_per_iter": n_s, "parallelism": f"chains x{world}"},
+            "config": {"workload": DESCR[args.workload] if args.scale == 1.0 else f"{args.workload} scaled n={n}",
+                       "chains_per_gpu": C, "burnin_iterations": burnin,
+                       "block_threads": sw.block_threads, "lds_bytes_per_chain": sw.lds_bytes,
+                       "swept_obs_per_iter": n_s, "parallelism": f"chains x{world}",
+                       "host_side": "none inside an iteration: hypers, shuffle, sweep, label alignment are device kernels (pmdi_gibbs_step)"},
             "obs_particles_per_sec": total_iters * n_s * P / dt,
+            "burnin_iters_per_sec": (burnin * C * world / burnin_s) if burnin else None,
             "sweep_kernel_ms": kernel_ms,
-            "sweep_busy_ms_per_step": busy_ms / args.steps,
-            "launch_concurrency": float(np.sum(launch_ms)) / busy_ms if busy_ms > 0 else None,
-            "sweep_only_iters_per_sec": args.steps * C * world / (busy_ms * 1e-3),
-            "median_chain_iters_per_sec_hint": "see profiles/README.md (per-chain latency distribution)",
-            "sweep_stats_last": {"ids_per_step": float(stats[:, 0].mean()) / n_s,
-                                 "classes_per_step": float(stats[:, 4].mean()) / n_s,
+            "sweep_only_iters_per_sec": C * world / (kernel_ms * 1e-3),
+            "per_chain_iters_per_sec": {"p50": float(1.0 / np.median(chain_s)), "slowest": float(1.0 / chain_s.max()),
+                                        "fastest": float(1.0 / chain_s.min()),
+                                        "note": "1 / (shader cycles of the chain's own sweep / shader clock), all chains co-resident"},
+            "sweep_stats_last": {"ids_per_step": float(stats[:, 0].mean()) / (n_s * K),
+                                 "classes_per_step": float(stats[:, 4].mean()) / (n_s * K),
                                  "resamples": float(stats[:, 1].mean()), "clones": float(stats[:, 2].mean()),
+                                 "clusters_evaluated_per_step": float(work[:, :, 0].sum()) / (C * n_s * K),
+                                 "clusters_updated_per_step": float(work[:, :, 1].sum()) / (C * n_s * K),
                                  "steps_fast_frac": float(stats[:, 5].sum()) / float(stats[:, 5:8].sum())},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "traffic_frac": (traffic / (kernel_ms * 1e-3) / HBM_PEAK) if traffic else None,
-                         "note": "achieved = dense-model algorithmic bytes (SURVEY 8d: 19392 B per obs*particle) / "
-                                 "kernel time. The kernel de-duplicates clusters and particle classes like the "
-                                 "reference does, so it moves far fewer bytes than the dense model and frac > 1 "
-                                 "is expected; `traffic` is the PMC-measured HBM bytes per sweep and `traffic_frac` that traffic / "
-                                 "sweep time / peak. A sweep ends with its slowest chain; converged chains are bound by dependent "
-                                 "latency, chains with many private clusters by HBM round trips (DESIGN.md section 6)."},
+                         "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+                         "algorithmic_bytes_per_sweep": alg, "dense_model_ratio": dense / alg,
+                         "note": "achieved = de-duplication-aware algorithmic bytes of one sweep (built from the kernel's work counters: "
+                                 "clusters evaluated / updated / cloned / moved, resampling events, per-step and per-sweep streams; "
+                                 "DESIGN.md section 6) / sweep time. dense_model_ratio = SURVEY 8d's dense-model bytes / these: the work "
+                                 "the reference's de-duplication (kept here) avoids. A sweep is bound by dependent latency, not by HBM."},
         }
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
         print(f"[bench] GPU part done: {out['value']:.1f} iters/s", file=sys.stderr, flush=True)
         if not args.no_cpu:
-            sec, secs = cpu_baseline(w, 4, args.cpu_iters)
-            out["cpu_baseline"] = {"value": 1.0 / sec, "unit": "Gibbs iters/s (sweep only, one chain)",
-                                   "cores": 1, "kind": "port",
-                                   "sample": f"oracle sweep, same workload, {args.cpu_iters} iterations after 4 warm-up "
-                                             f"iterations ({sum(secs):.1f} s of CPU work)"}
-            if args.cpu_all:
-                agg, cores = cpu_baseline_all_cores(args.scale, 4, max(4, args.cpu_iters // 3))
-                out["cpu_baseline_all_cores"] = {"value": agg, "unit": "Gibbs iters/s (sweep only, one chain per core, aggregate)",
-                                                 "cores": cores, "kind": "port",
-                                                 "sample": f"{cores} oracle processes at once, {max(4, args.cpu_iters // 3)} iterations each after 4 warm-up"}
+            order = np.argsort(costs)
+            pick = [int(order[int(q * (C - 1))]) for q in (0.5, 0.1, 0.9, 0.3, 0.7, 0.2, 0.8, 0.4)]   # settled chains across the cost range
+            states = [g.get(c) for c in pick]
+            out["cpu_baseline"] = cpu_baseline(w, args.scale, states, args.cpu_seconds)
+            out["gpu_over_all_host_cores"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+    g.close(); sw.close()
 
 
 if __name__ == "__main__":

@@ -215,6 +215,10 @@ int pmdi_gibbs_destroy(pmdi_gibbs *g);      /* before pmdi_destroy of its handle
  * (0-based labels), i.e. the rows generate_psm reads back from the CSV (consensus_map.jl:31-46). */
 int pmdi_gibbs_iterate(pmdi_gibbs *g, int64_t n_iter, uint8_t *samples, void *stream);
 
+/* The current allocations of every chain as bytes (0-based labels), n_chains x K x n, into device memory `out`:
+ * one retained sample in the layout pmdi_psm_counts_device reads.  Asynchronous on `stream`. */
+int pmdi_gibbs_pack_samples(pmdi_gibbs *g, uint8_t *out, void *stream);
+
 /* The pieces of one iteration as separate launches (tests; a host that wants to interleave its own work).
  * Order inside pmdi(): BEGIN (iteration counter += 1), HYPERS (:172-185), SWEEP (:165-171,188-350,373),
  * FEATSEL (:354-370, only with feature selection), ALIGN (:375). */
@@ -244,6 +248,22 @@ typedef struct {
 } pmdi_gibbs_view;
 int pmdi_gibbs_device_view(pmdi_gibbs *g, pmdi_gibbs_view *v);
 
+/* ---- pmdi()'s output files, byte-compatible with Julia's writedlm(io, row', ',') --------
+ * pmdi_csv_open writes the header of src/pmdi.jl:147-156 (MassParameter_k..., phi_a_b... [phi_1_1 when K = 1],
+ * ll, <name>_n<i>...; data_names NULL = "K1".."KK", :46-48); pmdi_csv_write_row one row [M; Phi; ll; s[1:n*K]]'
+ * (:158, :379; every field printed as Julia prints a Float64: shortest round-trip digits, "3.0", "1.0e-5");
+ * pmdi_csv_write_gibbs the same from a device-resident chain.  pmdi_csv_open_features / pmdi_csv_write_flags:
+ * the feature-selection file (:111-116, :380-382): <name>_d<d> header, rows of true/false.  Host-side code. */
+typedef struct pmdi_csv pmdi_csv;
+int pmdi_csv_open(const char *path, int32_t K, int64_t n, const char *const *data_names, pmdi_csv **out);
+int pmdi_csv_write_row(pmdi_csv *w, const double *M, const double *Phi, double ll, const int64_t *s);
+int pmdi_csv_write_gibbs(pmdi_csv *w, pmdi_gibbs *g, int32_t chain, double ll);
+int pmdi_csv_open_features(const char *path, int32_t K, const int32_t *D, const char *const *data_names, pmdi_csv **out);
+int pmdi_csv_write_flags(pmdi_csv *w, const uint8_t *flags);
+int pmdi_csv_close(pmdi_csv *w);
+/* Base.show(::Float64) of one number into out (NUL-terminated); returns its length or a negative error */
+int pmdi_format_float64(double x, char *out, int32_t cap);
+
 /* Debug: per-phase shader-clock totals of the last sweep (lane 0 of the chain's workgroup);
  * only when the environment variable PMDI_PHASE_TIMERS was set at pmdi_create. */
 int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);
@@ -253,8 +273,16 @@ int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);
  * launch the heaviest chains first. */
 int pmdi_chain_costs(pmdi_handle *h, int64_t *out);
 
+/* Work counters of the last sweep, n_chains x K x 8 Int64 per (chain, dataset): [0] clusters whose log-predictive
+ * was evaluated (the kernel evaluates only clusters a particle-class leader can reach, src/pmdi.jl:232; the
+ * reference's count of :218-220 is n_operations), [1] distinct clusters updated (cluster_add!, :300), [2] of which
+ * cloned (:297), [3] cluster ids moved by the renumbering of resampling events (:336), [4] resampling events that
+ * moved any.  bench.py builds its de-duplication-aware algorithmic byte count from these. */
+int pmdi_work_counters(pmdi_handle *h, int64_t *out);
+
 int pmdi_sum_D(const pmdi_handle *h);
 int pmdi_block_threads(const pmdi_handle *h);   /* threads per chain workgroup */
+int64_t pmdi_shader_clock_hz(const pmdi_handle *h); /* the clock pmdi_chain_costs counts in (hipDeviceAttributeClockRate) */
 int64_t pmdi_lds_bytes(const pmdi_handle *h);    /* LDS bytes per chain workgroup */
 int64_t pmdi_pool_cap(const pmdi_handle *h);
 int pmdi_categorical_L(const pmdi_handle *h, int32_t k);

@@ -12,7 +12,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PMDI_LIB_PATH") or os.path.join(_PKG, "libpmdi_hip.so")   # override: A/B builds only
-_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_hypers.hip", "pmdi_api.cpp")]
+_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_hypers.hip", "pmdi_api.cpp", "pmdi_csv.cpp")]
 _HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_PKG, "csrc", "pmdi_device.h"),
             os.path.join(_ROOT, "include", "pmdi_hip.h")]
 
@@ -30,7 +30,9 @@ EXPORTS = [
     "pmdi_cluster_stats", "pmdi_sum_D", "pmdi_pool_cap", "pmdi_categorical_L", "pmdi_phase_timers",
     "pmdi_block_threads", "pmdi_lds_bytes", "pmdi_chain_costs", "pmdi_label_counts_device", "pmdi_psm_counts_device",
     "pmdi_gibbs_create", "pmdi_gibbs_destroy", "pmdi_gibbs_iterate", "pmdi_gibbs_step", "pmdi_gibbs_iterations",
-    "pmdi_gibbs_get", "pmdi_gibbs_set", "pmdi_gibbs_results", "pmdi_gibbs_device_view",
+    "pmdi_gibbs_get", "pmdi_gibbs_set", "pmdi_gibbs_results", "pmdi_gibbs_device_view", "pmdi_gibbs_pack_samples",
+    "pmdi_csv_open", "pmdi_csv_write_row", "pmdi_csv_write_gibbs", "pmdi_csv_open_features", "pmdi_csv_write_flags",
+    "pmdi_csv_close", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz",
 ]
 
 
@@ -156,6 +158,10 @@ def lib():
     L.pmdi_label_counts_device.argtypes = [vp, vp, vp, vp]
     L.pmdi_chain_costs.restype = C.c_int
     L.pmdi_chain_costs.argtypes = [vp, vp]
+    L.pmdi_shader_clock_hz.restype = i64
+    L.pmdi_shader_clock_hz.argtypes = [vp]
+    L.pmdi_work_counters.restype = C.c_int
+    L.pmdi_work_counters.argtypes = [vp, vp]
     L.pmdi_phase_timers.restype = C.c_int
     L.pmdi_phase_timers.argtypes = [vp, i32, vp]
     L.pmdi_gibbs_create.restype = C.c_int
@@ -175,6 +181,21 @@ def lib():
     L.pmdi_gibbs_results.argtypes = [vp, vp, vp, vp, vp]
     L.pmdi_gibbs_device_view.restype = C.c_int
     L.pmdi_gibbs_device_view.argtypes = [vp, vp]
+    L.pmdi_gibbs_pack_samples.restype = C.c_int
+    L.pmdi_gibbs_pack_samples.argtypes = [vp, vp, vp]
+    L.pmdi_csv_open.restype = C.c_int
+    L.pmdi_csv_open.argtypes = [C.c_char_p, i32, i64, vp, C.POINTER(vp)]
+    L.pmdi_csv_write_row.restype = C.c_int
+    L.pmdi_csv_write_row.argtypes = [vp, vp, vp, dbl, vp]
+    L.pmdi_csv_write_gibbs.restype = C.c_int
+    L.pmdi_csv_write_gibbs.argtypes = [vp, vp, i32, dbl]
+    L.pmdi_csv_open_features.restype = C.c_int
+    L.pmdi_csv_open_features.argtypes = [C.c_char_p, i32, vp, vp, C.POINTER(vp)]
+    L.pmdi_csv_write_flags.restype = C.c_int
+    L.pmdi_csv_write_flags.argtypes = [vp, vp]
+    L.pmdi_csv_close.argtypes = [vp]
+    L.pmdi_format_float64.restype = C.c_int
+    L.pmdi_format_float64.argtypes = [dbl, C.c_char_p, i32]
     _lib = L
     return L
 
@@ -228,6 +249,7 @@ class Sweeper:
         self.cap = L.pmdi_pool_cap(h)
         self.block_threads = L.pmdi_block_threads(h)
         self.lds_bytes = L.pmdi_lds_bytes(h)
+        self.clock_hz = L.pmdi_shader_clock_hz(h)
         self.npairs = max(1, self.K * (self.K - 1) // 2)
         self._keep = None  # the library copied the data
 
@@ -308,6 +330,12 @@ class Sweeper:
         _check(lib().pmdi_chain_costs(self.h, _ptr(out)))
         return out
 
+    def work_counters(self):
+        """(n_chains, K, 8) int64: evaluated / updated / cloned clusters, moved ids, move events (pmdi_work_counters)."""
+        out = np.zeros((self.C, self.K, 8), dtype=np.int64)
+        _check(lib().pmdi_work_counters(self.h, _ptr(out)))
+        return out
+
     def phase_timers(self, chain=0):
         out = np.zeros(16, dtype=np.int64)
         _check(lib().pmdi_phase_timers(self.h, int(chain), _ptr(out)))
@@ -315,6 +343,54 @@ class Sweeper:
 
     def clusters(self, k, B):
         return ClusterBatch(self, k, B)
+
+
+class CsvWriter:
+    """pmdi()'s output file (src/pmdi.jl:147-158, 377-383) written by the native, byte-compatible writer."""
+
+    def __init__(self, path, K, n, data_names=None, feature_D=None):
+        names = None
+        if data_names is not None:
+            names = (C.c_char_p * K)(*[str(x).encode() for x in data_names])
+        h = C.c_void_p()
+        if feature_D is None:
+            _check(lib().pmdi_csv_open(str(path).encode(), int(K), int(n), names, C.byref(h)))
+        else:
+            D = np.ascontiguousarray(feature_D, dtype=np.int32)
+            _check(lib().pmdi_csv_open_features(str(path).encode(), int(K), _ptr(D), names, C.byref(h)))
+        self.h = h
+
+    def row(self, M, Phi, ll, s):
+        """s: (n, K) labels 1..N"""
+        M = np.ascontiguousarray(M, dtype=np.float64); Phi = np.ascontiguousarray(Phi, dtype=np.float64)
+        s_ = np.ascontiguousarray(np.asarray(s, dtype=np.int64).T)
+        _check(lib().pmdi_csv_write_row(self.h, _ptr(M), _ptr(Phi), float(ll), _ptr(s_)))
+
+    def gibbs_row(self, gibbs, chain, ll):
+        _check(lib().pmdi_csv_write_gibbs(self.h, gibbs.h, int(chain), float(ll)))
+
+    def flags(self, fl):
+        f = np.ascontiguousarray(fl, dtype=np.uint8)
+        _check(lib().pmdi_csv_write_flags(self.h, _ptr(f)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pmdi_csv_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_float64(x):
+    buf = C.create_string_buffer(64)
+    k = lib().pmdi_format_float64(float(x), buf, 64)
+    if k < 0:
+        raise PmdiError(k, lib().pmdi_last_error().decode())
+    return buf.value.decode()
 
 
 class GibbsView(C.Structure):
@@ -351,6 +427,9 @@ class Gibbs:
     def iterate(self, n_iter=1, samples_ptr=None, stream=None):
         _check(lib().pmdi_gibbs_iterate(self.h, int(n_iter), C.c_void_p(samples_ptr) if samples_ptr else None,
                                         C.c_void_p(stream) if stream else None))
+
+    def pack_samples(self, out_ptr, stream=None):
+        _check(lib().pmdi_gibbs_pack_samples(self.h, C.c_void_p(out_ptr), C.c_void_p(stream) if stream else None))
 
     def step(self, what, stream=None):
         _check(lib().pmdi_gibbs_step(self.h, int(what), C.c_void_p(stream) if stream else None))

@@ -112,6 +112,16 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
 
 }  // namespace
 
+// error reporting for the other translation units of the library (pmdi_csv.cpp, pmdi_comm.cpp)
+int pmdi_set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 struct pmdi_handle {
     pmdi_config cfg{};
     int T = 0;
@@ -132,7 +142,7 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work;
     bool have_order = false;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
@@ -198,6 +208,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.cost = (long long *)h->d_cost.p;
+    a.work = (long long *)h->d_work.p;
     a.chain_order = h->have_order ? (const int *)h->d_lorder.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
@@ -265,7 +276,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -411,8 +422,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             SweepArgs a;
             fill_sweep_common(h, a);
             a.terms_cap = tc; a.pid_lds = 1; a.pp_lds = 1;
-            if (pmdi_sweep_lds_bytes(a, T) > 150 * 1024) a.pid_lds = 0;   // class ids of K*P particles do not fit: global memory
-            if (pmdi_sweep_lds_bytes(a, T) > 150 * 1024) a.pp_lds = 0;    // nor does the per-particle step scratch
+            const size_t lds_target = (size_t)env_int("PMDI_LDS_TARGET", 150 * 1024);
+            if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pid_lds = 0;   // class ids of K*P particles do not fit: global memory
+            if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pp_lds = 0;    // nor does the per-particle step scratch
             pid_lds = a.pid_lds; pp_lds = a.pp_lds;
             if (pmdi_sweep_lds_bytes(a, T) > 160 * 1024)
                 return fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, T));
@@ -444,7 +456,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
         (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
-        (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
+        (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
         return bail(rc);
     if (hipMemset(h->d_group.p, 1, (size_t)C) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));   // first sweep: every chain is heavy
@@ -495,7 +507,27 @@ int pmdi_chain_costs(pmdi_handle *h, int64_t *out)
     HIP_TRY(hipMemcpy(out, h->d_cost.p, (size_t)h->cfg.n_chains * 8, hipMemcpyDeviceToHost));
     return PMDI_OK;
 }
+int pmdi_work_counters(pmdi_handle *h, int64_t *out)
+{
+    if (!h || !out) return fail(PMDI_E_ARG, "null argument");
+    const int C = h->cfg.n_chains, K = h->cfg.K;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<long long> w((size_t)C * PMDI_KMAX_I * 8);
+    HIP_TRY(hipMemcpy(w.data(), h->d_work.p, w.size() * 8, hipMemcpyDeviceToHost));
+    for (int c = 0; c < C; ++c)
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < 8; ++j) out[((size_t)c * K + k) * 8 + j] = w[((size_t)c * PMDI_KMAX_I + k) * 8 + j];
+    return PMDI_OK;
+}
 int pmdi_block_threads(const pmdi_handle *h) { return h ? h->T : 0; }
+int64_t pmdi_shader_clock_hz(const pmdi_handle *h)
+{
+    if (!h) return 0;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, h->cfg.device) != hipSuccess) return 0;
+    return (int64_t)khz * 1000;
+}
 int64_t pmdi_lds_bytes(const pmdi_handle *h)
 {
     if (!h) return 0;
@@ -1008,6 +1040,16 @@ int pmdi_gibbs_iterate(pmdi_gibbs *g, int64_t n_iter, uint8_t *samples, void *st
 }
 
 int64_t pmdi_gibbs_iterations(const pmdi_gibbs *g) { return g ? g->iter : 0; }
+
+int pmdi_gibbs_pack_samples(pmdi_gibbs *g, uint8_t *out, void *stream)
+{
+    if (!g || !out) return fail(PMDI_E_ARG, "null argument");
+    const pmdi_handle *h = g->h;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipError_t e = pmdi_launch_pack_samples(g->ga.s, out, (long long)h->cfg.n_chains * h->cfg.K * h->cfg.n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(PMDI_E_DEVICE, "pack-samples launch: %s", hipGetErrorString(e));
+    return PMDI_OK;
+}
 
 int pmdi_gibbs_device_view(pmdi_gibbs *g, pmdi_gibbs_view *v)
 {

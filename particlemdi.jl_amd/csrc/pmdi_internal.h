@@ -22,6 +22,10 @@ enum { SITE_DRAW = 0, SITE_RESAMPLE_U = 1, SITE_RESAMPLE_SLOT = 2, SITE_PSTAR = 
        SITE_SHUFFLE = 5, SITE_M_NORMAL = 6, SITE_M_ACCEPT = 7, SITE_GAMMA = 8, SITE_PHI_ALPHA = 9, SITE_PHI_GAMMA = 10,
        SITE_V = 11, SITE_ALIGN = 12, SITE_INIT_GAMMA = 13, SITE_INIT_PHI = 14, SITE_INIT_S = 15, SITE_INIT_FLAGS = 16 };
 enum { ST_NOPS = 0, ST_NRESAMPLE = 1, ST_NCLONES = 2, ST_MAXID = 3, ST_SUMCLASSES = 4 };
+// work counters per (chain, dataset), 8 slots each: clusters whose log-predictive was evaluated, distinct clusters
+// updated (deepcopy + cluster_add!), of which cloned, cluster ids moved down by the renumbering of a resampling event,
+// resampling events that moved any id
+enum { WK_EVAL = 0, WK_UPD = 1, WK_CLONE = 2, WK_MOVED = 3, WK_MOVE_EVENTS = 4 };
 
 // One dataset as the kernels see it.  Data are row-major on the device so
 // that an observation row is one contiguous, coalesced read.
@@ -91,6 +95,7 @@ struct SweepArgs {
     int *partstar;              // [chain][P]
     int *kstate;                // [chain][KMAX][2]  final (max id, particle buffer) per dataset
     long long *phase;           // [chain][16] per-phase shader-clock totals of lane 0, or null
+    long long *work;            // [chain][KMAX][8] work counters (WK_*), or null
     long long *cost;            // [chain] shader cycles this chain's sweep took (drives the next launch order)
     const int *chain_order;     // [n_chains] workgroup b sweeps chain chain_order[b] (heaviest first), or null
     const unsigned char *group_flag;  // [n_chains] 1 = heavy chain (many private clusters), 0 = light; or null

@@ -114,7 +114,7 @@ __device__ __forceinline__ void lds_barrier()
 // ---------------------------------------------------------------------------
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
-        need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v,
+        need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v, wk,
         kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, lab, misc, ph, stat,
         fl, news, total;
 };
@@ -134,6 +134,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
 #else
     c.stat = take(8 * 8);
 #endif
+    c.wk = take(PMDI_KMAX_I * 8 * 8);
     c.kmaxid = take(PMDI_KMAX_I * 4);
     c.kncls = take(PMDI_KMAX_I * 4);
     c.kcur = take(PMDI_KMAX_I * 4);
@@ -200,10 +201,11 @@ struct Sh {
     lu8 leaf_prog;
     lint kmaxid, kncls, kcur, knflag, khint, lab, misc;
     li64 ph, stat;   // phase timers; the sweep's counters (n_operations, ...), kept by lane 0
+    li64 wk;         // work counters per dataset (WK_*), kept by lane 0: what the dedup-aware byte model of bench.py is built from
     lu8 fl, news;
 };
 
-enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6, M_FAIL = 7, M_NLEAF = 8, M_NPROG = 9 };
+enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6, M_FAIL = 7, M_NLEAF = 8, M_NPROG = 9, M_ND = 10, M_MOVED = 11 };
 
 // class list of dataset k: slot r -> leader particle / class value.  The first cls_lds slots
 // live in LDS, the rest (burn-in only) in global memory.
@@ -328,6 +330,7 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
         sh.leaf_tot = (ldbl)(smem + c.leaf_tot); sh.leaf_carry = (ldbl)(smem + c.leaf_carry); sh.leaf_prog = (lu8)(smem + c.leaf_prog);
         sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag); sh.khint = (lint)(smem + c.khint);
         sh.lab = (lint)(smem + c.lab); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph); sh.stat = (li64)(smem + c.stat);
+        sh.wk = (li64)(smem + c.wk);
         sh.fl = (lu8)(smem + c.fl); sh.news = (lu8)(smem + c.news);
 }
 
@@ -749,7 +752,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     }
     for (int e = tid; e < a.item_cap; e += T) sh.ktab_minp[e] = PMDI_INF_I;        // it lies inside the list's LDS region
     if (tid == 0) {
-        sh.misc[M_NCLONE] = nclone; sh.misc[M_NCLS] = new_ncls;
+        sh.misc[M_NCLONE] = nclone; sh.misc[M_NCLS] = new_ncls; sh.misc[M_ND] = nd;
         sh.khint[k] = (gcensus && nd > PMDI_HT_SIZE / 4) ? 1 : 0;   // stay on the global census while it is needed
     }
     __syncthreads();
@@ -981,6 +984,8 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                         const int nid = (id <= oldmax) ? PMDI_NEWID(id) : 0;
                         const bool mv = nid != 0 && nid != id;
                         const int v = mv ? s.cn[id] : 0;
+                        const unsigned long long bmv = __ballot(mv);
+                        if (lane == 0 && bmv) atomicAdd(gen(&sh.misc[M_MOVED]), __popcll(bmv));
                         __syncthreads();
                         if (mv) s.cn[nid] = v;
                     }
@@ -1026,7 +1031,11 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 __syncthreads();
                 PHR(8);   // moves
                 const int nc2 = rebuild_classes<T>(pidk, cl, sh, P);
-                if (tid == 0) { sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1; }
+                if (tid == 0) {
+                    sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1;
+                    sh.wk[k * 8 + WK_MOVED] += sh.misc[M_MOVED]; sh.wk[k * 8 + WK_MOVE_EVENTS] += moves ? 1 : 0;
+                    sh.misc[M_MOVED] = 0;
+                }
                 __syncthreads();
                 PHR(9);   // classes
             }
@@ -1087,6 +1096,7 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
             st[5] = sh.stat[5]; st[6] = sh.stat[6]; st[7] = sh.stat[7];
             a.err[chain] = 0;
         }
+        if (a.work && tid < PMDI_KMAX_I * 8) a.work[(size_t)chain * PMDI_KMAX_I * 8 + tid] = sh.wk[tid];
     }
 }
 
@@ -1120,6 +1130,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         }                                                                       \
     } while (0)
     if (tid < 16) { sh.ph[tid] = 0; sh.misc[tid] = 0; }
+    if (tid < PMDI_KMAX_I * 8) sh.wk[tid] = 0;
     if (tid < PMDI_KMAX_I) sh.khint[tid] = 0;
     long long ph_t0 = 0, ph_r0 = 0;
     if (a.phase && tid == 0) { ph_last = clock64(); ph_t0 = ph_last; ph_r0 = wall_clock64(); }
@@ -1628,6 +1639,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 if (sh.misc[M_FAIL]) { failed = 1; break; }
                 nclone = sh.misc[M_NCLONE];
                 new_ncls = sh.misc[M_NCLS];
+                nd = sh.misc[M_ND];
             }
             }
             if (tid == 0) {
@@ -1637,6 +1649,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 sh.stat[2] += nclone;
                 if (maxid + nclone > sh.stat[3]) sh.stat[3] = maxid + nclone;
                 sh.kmaxid[k] = maxid + nclone; sh.kncls[k] = new_ncls;
+                sh.wk[k * 8 + WK_EVAL] += nneed; sh.wk[k * 8 + WK_UPD] += ustep ? 1 : nd; sh.wk[k * 8 + WK_CLONE] += nclone;
             }
             __syncthreads();
 #undef FRESH_LANE_IDS

@@ -1,14 +1,14 @@
-"""Host-side hyper-parameter updates of ParticleMDI (they stay on the host by
-design: BASELINE.json north_star).
+"""TEST INFRASTRUCTURE: a second, independently written restatement of src/update_hypers.jl and
+align_labels! (src/misc.jl:61-96) on numpy arrays, used to cross-check the C oracle
+(oracle/pmdi_oracle_hypers.c) in tests/test_oracle_hypers.py.  It was the product's host mirror in
+round 1; the product now runs these updates on the device (csrc/pmdi_hypers.hip).
 
-Restates src/update_hypers.jl and align_labels! (src/misc.jl:61-96) on numpy
-arrays.  The N^K tables (c_combn, Gamma_c, Phi_index; src/pmdi.jl:69-92) are
-held as K-dimensional arrays: row i of the reference's tables is the base-N
-digit vector of i with column k the (k-1)-th digit, i.e. axis k-1 of an
-(N,)*K Fortran-ordered array.
+The N^K tables (c_combn, Gamma_c, Phi_index; src/pmdi.jl:69-92) are held as K-dimensional arrays:
+row i of the reference's tables is the base-N digit vector of i with column k the (k-1)-th digit,
+i.e. axis k-1 of an (N,)*K array.
 
-Random numbers here come from numpy's Generator; they are host-side draws
-(M, gamma, Phi, v, label swaps) and are not part of the device parity contract.
+Draws: `draws` is an object with uniform/normal/gamma(…, it, pos, k, site) methods -- the oracle's
+Philox samplers in the cross-check (same variates as the C restatement), numpy's Generator otherwise.
 """
 import numpy as np
 from scipy.special import gammaln
@@ -24,11 +24,27 @@ def phi_lab(K):
     return np.array([(a, b) for a in range(K - 1) for b in range(a + 1, K)], dtype=np.int64)
 
 
+class NumpyDraws:
+    def __init__(self, rng):
+        self.rng = rng
+
+    def uniform(self, it, pos, k, site):
+        return self.rng.random()
+
+    def normal(self, it, pos, k, site):
+        return self.rng.normal()
+
+    def gamma(self, shape, it, pos, k, site):
+        return self.rng.gamma(shape, 1.0)
+
+
 class HyperState:
     """M, gamma, Phi, v, Z of one chain (src/pmdi.jl:59-96)."""
 
-    def __init__(self, n_obs, N, K, rng):
+    def __init__(self, n_obs, N, K, rng, draws=None):
         self.n, self.N, self.K, self.rng = int(n_obs), int(N), int(K), rng
+        self.draws = draws or NumpyDraws(rng)
+        self.it = 0
         self.M = np.ones(K) * 2.0                                           # :59
         self.gamma = rng.gamma(1.0 / N, 1.0, size=(N, K)) + EPS             # :60
         self.npairs = K * (K - 1) // 2 if K > 1 else 1
@@ -72,7 +88,7 @@ class HyperState:
 
     # -- src/update_hypers.jl -------------------------------------------------
     def update_v(self):                                                     # :1-3
-        self.v = self.rng.gamma(self.n, 1.0 / self.Z)
+        self.v = self.draws.gamma(self.n, self.it, 0, 0, 11) * (1.0 / self.Z)
         return self.v
 
     def update_Z(self):                                                     # :29-39
@@ -86,7 +102,7 @@ class HyperState:
             cur = self.M[k]
             ll = -gamma_dist.logpdf(g, cur / N, scale=1.0).sum()
             ll0 = -gamma_dist.logpdf(cur, 2.0, scale=0.25)
-            prop = cur + self.rng.normal() / 10.0
+            prop = cur + self.draws.normal(self.it, 0, k, 6) / 10.0
             if prop <= 0.0:
                 alpha = 0.0
             else:
@@ -94,7 +110,7 @@ class HyperState:
                 nll0 = -gamma_dist.logpdf(prop, 2.0, scale=0.25)
                 with np.errstate(over="ignore"):
                     alpha = np.exp(-nll - nll0 + ll + ll0)
-            if self.rng.random() < alpha:
+            if self.draws.uniform(self.it, 0, k, 7) < alpha:
                 self.M[k] = prop
 
     def update_gamma(self):                                                 # :64-92
@@ -110,7 +126,7 @@ class HyperState:
                 sl = tuple(sl)
                 old = self.gamma[nn, k] + 0.0
                 beta_star = 1.0 + self.v * nt[sl].sum() / self.gamma[nn, k]
-                self.gamma[nn, k] = self.rng.gamma(alpha_star[nn, k], 1.0 / beta_star) + EPS
+                self.gamma[nn, k] = self.draws.gamma(alpha_star[nn, k], self.it, nn, k, 8) * (1.0 / beta_star) + EPS
                 nt[sl] *= self.gamma[nn, k] / old
 
     def update_Phi(self):                                                   # :95-128
@@ -126,8 +142,11 @@ class HyperState:
             r = np.arange(n_agree + 1)
             w = gammaln(r + 1.0) + binom.logpmf(r, n_agree, 0.5) - r * np.log(1.0 / beta_star)
             w = np.exp(w - w.max())
-            alpha_star = 1.0 + self.rng.choice(n_agree + 1, p=w / w.sum())
-            self.Phi[i] = self.rng.gamma(alpha_star, 1.0 / beta_star)
+            t = self.draws.uniform(self.it, 0, i, 9) * w.sum()
+            pick = min(int(np.searchsorted(np.cumsum(w), t, side="left")), n_agree)   # StatsBase sample(::Weights)
+            self.pick = pick
+            alpha_star = 1.0 + pick
+            self.Phi[i] = self.draws.gamma(alpha_star, self.it, 0, i, 10) * (1.0 / beta_star)
             nt[mask] *= (1.0 + self.Phi[i]) / (1.0 + cur)
 
     def Pi(self):                                                           # src/pmdi.jl:179
@@ -171,7 +190,7 @@ class HyperState:
             _, first = np.unique(col, return_index=True)
             occupied = col[np.sort(first)].tolist()                          # unique(), first appearance
             perm = np.arange(N + 1)                                          # label of the start of this k -> label now
-            for label in occupied:
+            for oi, label in enumerate(occupied):
                 a = label - 1
                 if T[(k, others[0])][a].sum() == 0:                          # all(label_ind .== false)
                     continue
@@ -187,7 +206,7 @@ class HyperState:
                     lps_swap = (c_ln * rel + c_nl * rel).sum()
                     with np.errstate(over="ignore"):
                         accept = np.exp(lps_swap - lps)
-                    if self.rng.random() < accept:
+                    if self.draws.uniform(self.it, oi * N + new_label - 1, k, 12) < accept:
                         for j in others:
                             T[(k, j)][[a, b], :] = T[(k, j)][[b, a], :]
                             T[(j, k)][:, [a, b]] = T[(j, k)][:, [b, a]]
@@ -211,7 +230,7 @@ class HyperState:
             # pair order in relevant_Phis follows Phi_lab; columns of label_rows follow `others`;
             # both enumerate the other datasets in increasing order, as the reference does
             occupied = list(dict.fromkeys(s[:, k].tolist()))               # unique(), first appearance
-            for label in occupied:
+            for oi, label in enumerate(occupied):
                 label_ind = s[:, k] == label
                 if not label_ind.any():
                     continue
@@ -226,7 +245,7 @@ class HyperState:
                     lps_swap = (ce(label_rows, new_label) * rel + ce(new_rows, label) * rel).sum()
                     with np.errstate(over="ignore"):
                         accept = np.exp(lps_swap - lps)
-                    if self.rng.random() < accept:
+                    if self.draws.uniform(self.it, oi * N + new_label - 1, k, 12) < accept:
                         s[label_ind, k] = new_label
                         s[new_ind, k] = label
                         gam[new_label - 1, k], gam[label - 1, k] = gam[label - 1, k], gam[new_label - 1, k]
