@@ -418,6 +418,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             if (tc < P) tc = P;
             if (tc < (T / 64) * 128) tc = (T / 64) * 128;
             if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
+            if (tc < 384) tc = 384;                                   // the known-prefix label table (3 x 256 ints) lives there
             terms_cap = tc;
             SweepArgs a;
             fill_sweep_common(h, a);

@@ -115,7 +115,7 @@ __device__ __forceinline__ void lds_barrier()
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
         need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v, wk,
-        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, lab, misc, ph, stat,
+        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, misc, ph, stat,
         fl, news, total;
 };
 
@@ -140,7 +140,6 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.kcur = take(PMDI_KMAX_I * 4);
     c.knflag = take(PMDI_KMAX_I * 4);
     c.khint = take(PMDI_KMAX_I * 4);
-    c.lab = take(256 * 3 * 4);
     c.leaf_i1 = take(64 * 4);
     c.leaf_n = take(64 * 4);
     c.leaf_tot = take(64 * 8);
@@ -329,7 +328,7 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
         sh.leaf_i1 = (lint)(smem + c.leaf_i1); sh.leaf_n = (lint)(smem + c.leaf_n);
         sh.leaf_tot = (ldbl)(smem + c.leaf_tot); sh.leaf_carry = (ldbl)(smem + c.leaf_carry); sh.leaf_prog = (lu8)(smem + c.leaf_prog);
         sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag); sh.khint = (lint)(smem + c.khint);
-        sh.lab = (lint)(smem + c.lab); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph); sh.stat = (li64)(smem + c.stat);
+        sh.lab = (lint)(smem + c.term); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph); sh.stat = (li64)(smem + c.stat);
         sh.wk = (li64)(smem + c.wk);
         sh.fl = (lu8)(smem + c.fl); sh.news = (lu8)(smem + c.news);
 }

@@ -98,32 +98,115 @@ def test_pmdi_driver_csv(pkg, tmp_path):
 @pytest.mark.parametrize("cfg,scale,P", [("cfg3", 0.05, 256), ("cfg4", 0.03, 256), ("cfg5", 0.015, 512), ("HL", 0.03, 256)])
 def test_baseline_configs_reduced_vs_oracle(pkg, O, cfg, scale, P):
     """Every BASELINE.json config (data types, K, N, D as specified; n and P reduced so that the
-    oracle finishes in seconds) run as a real Gibbs chain with host hyper-updates: device == oracle."""
+    oracle finishes in seconds) run as a real Gibbs chain (the oracle's hyper updates on the host): device == oracle."""
     from particlemdi_jl_amd import workloads
-    from particlemdi_jl_amd.hypers import HyperState
     w = workloads.make(cfg, scale)
     n, K, N = w["n"], w["K"], w["N"]
-    rng = np.random.default_rng(3)
-    hy = HyperState(n, N, K, rng)
+    if N ** K > 4e6:
+        N = 12                                  # the oracle's literal N^K tables (cfg4: 50^4)
+    hy = O.Hypers(n, N, K, seed=3)
     sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=1, seed=17)
     o = O.Oracle(w["data"], w["kinds"], N, P, seed=17)
-    order = np.arange(1, n + 1)
     n1 = max(1, int(np.floor(0.25 * n)))
-    fast = 0
     for it in range(1, 4):
-        rng.shuffle(order)
-        Pi = hy.step_pmdi_order()
-        rg = sw.sweep(it, hy.s[None], order[None], n1, Pi[None], hy.Phi[None])
-        ro = o.sweep(it, hy.s, order, n1, Pi, hy.Phi)
+        Pi = hy.step(it)
+        s, order = np.array(hy.s), np.array(hy.order)
+        rg = sw.sweep(it, s[None], order[None], n1, Pi[None], hy.Phi[None])
+        ro = o.sweep(it, s, order, n1, Pi, hy.Phi)
         assert (rg["s"][0] == ro["s"]).all() and int(rg["p_star"][0]) == ro["p_star"], f"{cfg} iteration {it}"
         assert np.allclose(rg["logweight"][0], ro["logweight"], rtol=1e-6)
         for key in ("n_operations", "n_resamples", "n_clones", "sum_classes"):
             assert rg["stats"][0][key] == ro["stats"][key]
-        fast += rg["stats"][0]["steps_fast"]
         hy.s[:] = ro["s"]
-        hy.align_labels()
+        hy.align_labels(it)
     if cfg == "cfg5":      # feature selection (the calc_logmarginal path) on the 200-feature datasets
-        fl, pr = sw.feature_select(3, hy.s[None])
-        of, op = o.feature_select(3, hy.s)
+        fl, pr = sw.feature_select(3, np.array(hy.s)[None])
+        of, op = o.feature_select(3, np.array(hy.s))
         assert (fl[0] == np.concatenate(of)).all()
         assert np.allclose(pr[0], np.concatenate(op), rtol=1e-9)
+
+
+# burn-in iterations on the device before the compared one (a mid-chain state: tens of live clusters, resampling active).
+# cfg5 starts from the planted clustering with 5 % of the labels scrambled instead of the random start of
+# src/pmdi.jl:63-66: its first sweeps from a random start (hundreds of particle classes at P = 4 096, N = 50) take
+# minutes each, which the GPU test budget does not have.
+FULL = {"cfg3": 3, "HL": 3, "cfg4": 2, "cfg5": 1}
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "HL", "cfg4", "cfg5"])
+def test_full_size_mid_chain_iteration_vs_oracle(pkg, O, cfg):
+    """BASELINE.json's configs at their FULL sizes (n, K, D, N, P as stated; cfg4: P = 2 048, N = 50; cfg5: P = 4 096,
+    N = 50, D = 200, feature selection on): a chain is burnt in on the device, then ONE whole iteration is compared
+    piece by piece with the oracle from the same state -- hyper-parameter kernel, sweep (allocations, p_star,
+    counters, log-weights, T5 invariants on the exported state), feature selection, label alignment."""
+    from particlemdi_jl_amd import workloads
+    w = workloads.make(cfg)
+    n, K, N, P = w["n"], w["K"], w["N"], w["P"]
+    assert (n, N, P) == {"cfg3": (5000, 30, 1024), "HL": (10000, 20, 1024), "cfg4": (10000, 50, 2048), "cfg5": (20000, 50, 4096)}[cfg]
+    fsel = cfg == "cfg5"
+    base_seed, C = 41, (4 if P <= 1024 else 2)
+    sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=C, seed=base_seed)
+    g = pkg.Gibbs(sw, rho=0.25, feature_select=fsel)
+    n1 = g.n1
+    if cfg == "cfg5":
+        rng = np.random.default_rng(2)
+        for cc in range(C):
+            s0 = np.repeat((w["truth"] + 1)[:, None], K, axis=1)
+            idx = rng.random((n, K)) < 0.05
+            s0[idx] = rng.integers(1, N + 1, size=int(idx.sum()))
+            g.set(cc, s=s0)
+    g.iterate(FULL[cfg])
+    # the chain whose last burn-in sweep resampled most (a chain can collapse into one cluster per dataset, where
+    # every step is unanimous and nothing is resampled: not the state this test is after)
+    c = int(np.argmax(g.results()["stats"][:, 1]))
+    seed = base_seed + c
+    it = FULL[cfg] + 1
+    st0 = g.get(c)
+    # ---- hyper-parameter kernel against the literal N^K restatement from the same state
+    hy = O.Hypers(n, N, K, seed=seed)
+    hy.M, hy.gamma, hy.gamma0, hy.Phi, hy.v, hy.Z = st0["M"], st0["gamma"], st0["gamma0"], st0["Phi"], st0["v"], st0["Z"]
+    hy.s[:] = st0["s"]; hy.order[:] = st0["order"]
+    hy.step(it)
+    g.step(pkg.STEP_BEGIN); g.step(pkg.STEP_HYPERS)
+    st1 = g.get(c)
+    assert (st1["order"] == np.array(hy.order)).all()
+    for key in ("M", "gamma", "Phi"):
+        assert np.allclose(st1[key], getattr(hy, key), rtol=1e-9), key
+    assert np.isclose(st1["v"], hy.v, rtol=1e-9) and np.isclose(st1["Z"], hy.Z, rtol=1e-9)
+    # ---- the sweep at full size: same inputs on both sides (the device's post-update hyper-parameters)
+    Pi = st1["gamma"] / st1["gamma"].sum(axis=0, keepdims=True)
+    orc = O.Oracle(w["data"], w["kinds"], N, P, seed=seed)
+    flags = [st1["flags"][sum(w["D"][:k]):sum(w["D"][:k + 1])] for k in range(K)]
+    ro = orc.sweep(it, st1["s"], st1["order"], n1, Pi, st1["Phi"], flags, lw_init=1.0)
+    g.step(pkg.STEP_SWEEP)
+    res = g.results()
+    st2 = g.get(c)
+    print(f"{cfg}: chain {c}, oracle sweep {ro['stats']['seconds']:.1f} s, stats {ro['stats']}")
+    assert (st2["s"] == ro["s"]).all(), f"{cfg}: allocations differ from the oracle at full size"
+    assert int(res["p_star"][c]) == ro["p_star"]
+    for j, key in enumerate(("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")):
+        assert res["stats"][c, j] == ro["stats"][key], key
+    assert np.allclose(res["logweight"][c], ro["logweight"], rtol=1e-6, atol=1e-6)       # north_star tolerance
+    assert ro["stats"]["n_resamples"] > 0 and ro["stats"]["n_operations"] > 2 * K * (n - n1 + 1)   # a genuinely mid-chain state
+    wk = sw.work_counters()[c]
+    assert wk[:, 2].sum() == ro["stats"]["n_clones"] and (wk[:, 0] <= res["stats"][c, 0]).all()
+    dev_state, ora_state = sw.export_state(c), orc.export()
+    t5_invariants(dev_state, N, P, K, n)
+    assert (dev_state["particle"] == ora_state["particle"]).all()
+    assert (dev_state["max_id"] == ora_state["max_id"]).all()
+    for k in range(K):
+        m = int(ora_state["max_id"][k])
+        assert (dev_state["counts"][k][:m] == ora_state["counts"][k][:m]).all()
+        assert (dev_state["cluster_n"][k][:m] == ora_state["cluster_n"][k][:m]).all()
+    # ---- feature selection (cfg5) and label alignment from the same state
+    if fsel:
+        g.step(pkg.STEP_FEATSEL)
+        of, _ = orc.feature_select(it, ro["s"])
+        assert (g.get(c)["flags"] == np.concatenate(of)).all()
+    hy.s[:] = ro["s"]
+    hy.gamma, hy.Phi = st1["gamma"], st1["Phi"]
+    hy.align_labels(it)
+    g.step(pkg.STEP_ALIGN)
+    st3 = g.get(c)
+    assert (st3["s"] == np.array(hy.s)).all() and (st3["gamma"] == hy.gamma).all()
+    g.close(); sw.close(); orc.close(); hy.close()

@@ -43,6 +43,29 @@ def test_T5_invariants(O, P, iters):
     t5_invariants(o.export(), N, P, K, n)
 
 
+def test_T5_invariants_in___pmdi_mode(O):
+    """test/runtests.jl:155 runs __pmdi (history permuted on resample: src/__pmdi.jl:285 = q2_mode 1) with
+    P = 1024 for 100 iterations on 3 x (100 x 16); the same shape here, hyper-parameters from the restated updates."""
+    rng = np.random.default_rng(15)
+    data = [np.vstack([rng.normal(2, 1, (50, 16)), rng.normal(-2, 1, (50, 16))]) for _ in range(3)]
+    N, K, n, P = 10, 3, 100, 1024
+    o = O.Oracle(data, ["gaussian"] * 3, N, P, seed=9, q2_mode=1)
+    hy = O.Hypers(n, N, K, seed=9)
+    resamples = 0
+    for it in range(1, 101):
+        Pi = hy.step(it)
+        r = o.sweep(it, np.array(hy.s), np.array(hy.order), 25, Pi, hy.Phi)
+        hy.s[:] = r["s"]
+        hy.align_labels(it)
+        resamples += r["stats"]["n_resamples"]
+        if it in (1, 2, 50, 100):
+            t5_invariants(o.export(), N, P, K, n)
+    assert resamples > 0
+    s = np.array(hy.s)
+    assert s.min() >= 1 and s.max() <= N
+    hy.close()
+
+
 def test_determinism_and_cost_switch(O):
     rng = np.random.default_rng(6)
     data, kinds = make_mixed(rng, 150)
