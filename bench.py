@@ -170,6 +170,13 @@ def main():
 
     G.build()
     pkg = G.load_package()
+    comm = None
+    if dist is not None:
+        # the exchange step goes through the library's own RCCL communicator (pmdi_allgather_samples); torch.distributed only
+        # carries the 128-byte unique id to the other ranks and the barriers / max-over-ranks of the timing contract
+        uid = torch.from_numpy(pkg.Comm.unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8)).to(dev)
+        dist.broadcast(uid, 0)
+        comm = pkg.Comm(local_rank, world, rank, uid.cpu().numpy())
     from particlemdi_jl_amd import workloads
 
     w = workloads.make(args.workload, args.scale)
@@ -232,9 +239,9 @@ def main():
         iteration(events)
         g.pack_samples(samples.data_ptr() + k * per, sp)       # retained allocation sample of this iteration (uint8): the PSM's input
     torch.cuda.synchronize()
-    if dist is not None:
+    if comm is not None:
         gathered = torch.empty((world,) + tuple(samples.shape), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered, samples)      # RCCL over xGMI: PSM input
+        comm.allgather(samples.data_ptr(), gathered.data_ptr(), samples.numel(), sp)      # RCCL over xGMI: the PSM's input
     barrier()
     dt = time.perf_counter() - t0
     res = g.results()
@@ -296,6 +303,8 @@ def main():
                                  "DESIGN.md section 6) / sweep time. dense_model_ratio = SURVEY 8d's dense-model bytes / these: the work "
                                  "the reference's de-duplication (kept here) avoids. A sweep is bound by dependent latency, not by HBM."},
         }
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -264,6 +264,28 @@ int pmdi_csv_close(pmdi_csv *w);
 /* Base.show(::Float64) of one number into out (NUL-terminated); returns its length or a negative error */
 int pmdi_format_float64(double x, char *out, int32_t cap);
 
+/* ---- the one exchange step of the multi-GPU path ------------------------------------------
+ * Chains are independent (no data-path collective).  After sampling, the retained allocation samples of every
+ * rank (uint8 labels, layout of pmdi_gibbs_iterate's `samples`) are all-gathered with RCCL over xGMI so that every
+ * GPU can build its row block of the posterior-similarity matrix (pmdi_psm_counts_device; consumer generate_psm,
+ * src/output_analysis/consensus_map.jl:31-65).  Two ways to form the communicator:
+ *   one process per GPU:  rank 0 calls pmdi_comm_unique_id, the host distributes the 128 bytes (MPI, a file,
+ *                         torch.distributed ...), every rank calls pmdi_comm_init_rank;
+ *   one process, G GPUs:  pmdi_comm_init_all fills G communicators (devices NULL = 0..G-1).
+ * pmdi_allgather_samples: entry i of comms/send/recv/streams belongs to local communicator i (n_local = 1 in the
+ * one-process-per-GPU case); recv[i] receives n_ranks x bytes_per_rank bytes in rank order.  Asynchronous on the
+ * given streams (hipStream_t, NULL entries / NULL array = default stream).  RCCL is loaded at first use. */
+#define PMDI_COMM_ID_BYTES 128
+typedef struct pmdi_comm pmdi_comm;
+int pmdi_comm_unique_id(uint8_t id[PMDI_COMM_ID_BYTES]);
+int pmdi_comm_init_rank(int32_t device, int32_t n_ranks, int32_t rank, const uint8_t id[PMDI_COMM_ID_BYTES], pmdi_comm **out);
+int pmdi_comm_init_all(int32_t n_devices, const int32_t *devices, pmdi_comm **out);
+int pmdi_comm_destroy(pmdi_comm *c);
+int pmdi_comm_rank(const pmdi_comm *c);
+int pmdi_comm_size(const pmdi_comm *c);
+int pmdi_allgather_samples(pmdi_comm *const *comms, int32_t n_local, const uint8_t *const *send, uint8_t *const *recv,
+                           int64_t bytes_per_rank, void *const *streams);
+
 /* Debug: per-phase shader-clock totals of the last sweep (lane 0 of the chain's workgroup);
  * only when the environment variable PMDI_PHASE_TIMERS was set at pmdi_create. */
 int pmdi_phase_timers(pmdi_handle *h, int32_t chain, int64_t *out16);

@@ -12,7 +12,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PMDI_LIB_PATH") or os.path.join(_PKG, "libpmdi_hip.so")   # override: A/B builds only
-_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_hypers.hip", "pmdi_api.cpp", "pmdi_csv.cpp")]
+_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_hypers.hip", "pmdi_api.cpp", "pmdi_csv.cpp", "pmdi_comm.cpp")]
 _HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_PKG, "csrc", "pmdi_device.h"),
             os.path.join(_ROOT, "include", "pmdi_hip.h")]
 
@@ -33,6 +33,8 @@ EXPORTS = [
     "pmdi_gibbs_get", "pmdi_gibbs_set", "pmdi_gibbs_results", "pmdi_gibbs_device_view", "pmdi_gibbs_pack_samples",
     "pmdi_csv_open", "pmdi_csv_write_row", "pmdi_csv_write_gibbs", "pmdi_csv_open_features", "pmdi_csv_write_flags",
     "pmdi_csv_close", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz",
+    "pmdi_comm_unique_id", "pmdi_comm_init_rank", "pmdi_comm_init_all", "pmdi_comm_destroy", "pmdi_comm_rank", "pmdi_comm_size",
+    "pmdi_allgather_samples",
 ]
 
 
@@ -158,6 +160,17 @@ def lib():
     L.pmdi_label_counts_device.argtypes = [vp, vp, vp, vp]
     L.pmdi_chain_costs.restype = C.c_int
     L.pmdi_chain_costs.argtypes = [vp, vp]
+    L.pmdi_comm_unique_id.restype = C.c_int
+    L.pmdi_comm_unique_id.argtypes = [vp]
+    L.pmdi_comm_init_rank.restype = C.c_int
+    L.pmdi_comm_init_rank.argtypes = [i32, i32, i32, vp, C.POINTER(vp)]
+    L.pmdi_comm_init_all.restype = C.c_int
+    L.pmdi_comm_init_all.argtypes = [i32, vp, vp]
+    L.pmdi_comm_destroy.argtypes = [vp]
+    L.pmdi_comm_rank.argtypes = [vp]
+    L.pmdi_comm_size.argtypes = [vp]
+    L.pmdi_allgather_samples.restype = C.c_int
+    L.pmdi_allgather_samples.argtypes = [vp, i32, vp, vp, i64, vp]
     L.pmdi_shader_clock_hz.restype = i64
     L.pmdi_shader_clock_hz.argtypes = [vp]
     L.pmdi_work_counters.restype = C.c_int
@@ -391,6 +404,40 @@ def format_float64(x):
     if k < 0:
         raise PmdiError(k, lib().pmdi_last_error().decode())
     return buf.value.decode()
+
+
+class Comm:
+    """One rank of the RCCL communicator behind pmdi_allgather_samples (one process per GPU)."""
+
+    def __init__(self, device, n_ranks, rank, unique_id):
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(lib().pmdi_comm_init_rank(int(device), int(n_ranks), int(rank), _ptr(uid), C.byref(h)))
+        self.h, self.n_ranks, self.rank = h, int(n_ranks), int(rank)
+
+    @staticmethod
+    def unique_id():
+        uid = np.zeros(128, dtype=np.uint8)
+        _check(lib().pmdi_comm_unique_id(_ptr(uid)))
+        return uid
+
+    def allgather(self, send_ptr, recv_ptr, bytes_per_rank, stream=None):
+        comms = (C.c_void_p * 1)(self.h)
+        send = (C.c_void_p * 1)(send_ptr)
+        recv = (C.c_void_p * 1)(recv_ptr)
+        st = (C.c_void_p * 1)(stream or None)
+        _check(lib().pmdi_allgather_samples(comms, 1, send, recv, int(bytes_per_rank), st))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().pmdi_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class GibbsView(C.Structure):

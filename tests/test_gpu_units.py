@@ -136,3 +136,44 @@ def test_psm_counts_on_device(pkg, O, S, K, n, lo, hi, nlab):
     rows_dev = psm.psm_rows(torch.from_numpy(smp).cuda(), lo, hi, n_labels=nlab).cpu().numpy()
     rows_host = psm.psm_rows(smp, lo, hi, host=True)
     assert (rows_dev == rows_host).all()
+
+
+def test_allgather_samples_through_the_c_abi(pkg, O):
+    """the one collective of the path behind the C ABI (pmdi_comm_*, pmdi_allgather_samples), here in its
+    one-rank form on the one GPU of the test box (both ways of forming the communicator), feeding the PSM counts:
+    chains -> retained samples -> RCCL all-gather -> pmdi_psm_counts_device == the oracle's counts."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(12)
+    n, N, K, P, chains, T = 96, 5, 2, 32, 3, 4
+    z = rng.integers(0, 3, n)
+    data = [rng.normal(size=(n, 3)) + 2.0 * (z[:, None] - 1) for _ in range(K)]
+    sw = pkg.Sweeper(data, ["gaussian"] * K, N, P, n_chains=chains, seed=4)
+    g = pkg.Gibbs(sw, rho=0.25)
+    smp = torch.zeros((T, chains, K, n), dtype=torch.uint8, device="cuda")
+    g.iterate(T, samples_ptr=smp.data_ptr())
+    g.results()
+    comm = pkg.Comm(0, 1, 0, pkg.Comm.unique_id())
+    out = torch.zeros((1,) + tuple(smp.shape), dtype=torch.uint8, device="cuda")
+    comm.allgather(smp.data_ptr(), out.data_ptr(), smp.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (out[0] == smp).all()
+    comm.close()
+    # one process, G devices (G = 1 here): pmdi_comm_init_all + the group form of the call
+    L = pkg.lib()
+    h = (C.c_void_p * 1)()
+    assert L.pmdi_comm_init_all(1, None, h) == 0, L.pmdi_last_error()
+    assert L.pmdi_comm_size(h[0]) == 1 and L.pmdi_comm_rank(h[0]) == 0
+    out2 = torch.zeros_like(out)
+    send = (C.c_void_p * 1)(smp.data_ptr()); recv = (C.c_void_p * 1)(out2.data_ptr())
+    assert L.pmdi_allgather_samples(h, 1, send, recv, smp.numel(), None) == 0, L.pmdi_last_error()
+    torch.cuda.synchronize()
+    assert (out2[0] == smp).all()
+    L.pmdi_comm_destroy(h[0])
+    # the consumer: pooled samples (S = T * chains, K, n) -> co-clustering counts
+    from particlemdi_jl_amd.psm import psm_counts_device
+    pooled = out[0].reshape(T * chains, K, n).contiguous()
+    got = psm_counts_device(pooled, 0, n, n_labels=N).cpu().numpy()
+    want = O.psm_counts(pooled.cpu().numpy(), 0, n)
+    assert (got == want).all()
+    g.close(); sw.close()
