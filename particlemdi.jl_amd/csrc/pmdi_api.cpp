@@ -142,7 +142,7 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos;
     bool have_order = false;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
@@ -209,6 +209,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.cost = (long long *)h->d_cost.p;
     a.work = (long long *)h->d_work.p;
+    a.anclog = (int *)h->d_anclog.p; a.evpos = (int *)h->d_evpos.p;
     a.chain_order = h->have_order ? (const int *)h->d_lorder.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
@@ -276,7 +277,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -305,7 +306,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if (P > 1048575) return fail(PMDI_E_ARG, "P=%d too large", P);
     if (cfg->n_chains < 1) return fail(PMDI_E_ARG, "n_chains must be >= 1");
     if (cfg->q1_mode < 0 || cfg->q1_mode > 1) return fail(PMDI_E_ARG, "q1_mode must be 0 or 1");
-    if (cfg->q2_mode != 0) return fail(PMDI_E_ARG, "q2_mode=1 (__pmdi history permutation) is not implemented yet");
+    if (cfg->q2_mode < 0 || cfg->q2_mode > 1) return fail(PMDI_E_ARG, "q2_mode must be 0 or 1");
     long long cap = cfg->pool_cap > 0 ? cfg->pool_cap : (long long)N * P + 1;
     if (cap > (long long)N * P + 1) cap = (long long)N * P + 1;
     if (cap < N + 2) return fail(PMDI_E_ARG, "pool_cap too small");
@@ -459,6 +460,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
         (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
+        return bail(rc);
+    if (cfg->q2_mode == 1 &&       // ancestor log of the resampling events: up to one per swept observation
+        ((rc = h->d_anclog.ensure((size_t)C * (size_t)n * P * 4)) || (rc = h->d_evpos.ensure((size_t)C * 2 * (size_t)n * 4))))
         return bail(rc);
     if (hipMemset(h->d_group.p, 1, (size_t)C) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));   // first sweep: every chain is heavy
 

@@ -96,6 +96,8 @@ struct SweepArgs {
     int *kstate;                // [chain][KMAX][2]  final (max id, particle buffer) per dataset
     long long *phase;           // [chain][16] per-phase shader-clock totals of lane 0, or null
     long long *work;            // [chain][KMAX][8] work counters (WK_*), or null
+    int *anclog;                // q2_mode 1: [chain][n-n1+1][P] ancestor table of every resampling event
+    int *evpos;                 // q2_mode 1: [chain][2][n-n1+1] position of every resampling event; the selected particle's lineage
     long long *cost;            // [chain] shader cycles this chain's sweep took (drives the next launch order)
     const int *chain_order;     // [n_chains] workgroup b sweeps chain chain_order[b] (heaviest first), or null
     const unsigned char *group_flag;  // [n_chains] 1 = heavy chain (many private clusters), 0 = light; or null

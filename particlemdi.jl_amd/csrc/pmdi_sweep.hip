@@ -881,6 +881,15 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             const Dual<int> ancp = dual(a.pp_lds != 0, sh.kv, make_ks(a.ds[0], chain).kv);
             for (int p = tid; p < P; p += T) ancp[p] = (p == 0) ? 0 : (p <= js ? pstar_raw[p - 1] : pstar_raw[p]);
             __syncthreads();
+            if (a.q2) {
+                // __pmdi() permutes the allocation history on every resampling (src/__pmdi.jl:285: sstar[:,:,k] = sstar[partstar,:,k]);
+                // here the ancestor table of the event is logged and the selected particle's lineage is traced back once,
+                // at the end of the sweep (sweep_final): same trajectory, n*P bytes moved per event less
+                const long long ev = sh.stat[1] - 1;
+                const gint lg = glob(a.anclog) + ((size_t)chain * (size_t)(n - n1 + 1) + (size_t)ev) * P;
+                for (int p = tid; p < P; p += T) lg[p] = ancp[p];
+                if (tid == 0) glob(a.evpos)[(size_t)chain * 2 * (size_t)(n - n1 + 1) + ev] = (int)pos;
+            }
             PHR(2);   // search + ancestors
             for (int k = 0; k < K; ++k) {                         // src/pmdi.jl:320-340
                 const DsetDev &d = a.ds[k];
@@ -1065,14 +1074,35 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
         }
         __syncthreads();
         const int pstar = sh.misc[M_PSTAR];
+        // q2_mode 1 (__pmdi): the history was permuted by every resampling event at or after a position, i.e. the value
+        // that ends up in slot p_star was written into the slot its lineage occupied then.  lin[e] = that slot for the
+        // positions in (evpos[e-1], evpos[e]]; positions after the last event read slot p_star itself.
+        const int nev = a.q2 ? (int)sh.stat[1] : 0;
+        const gint evp = a.q2 ? glob(a.evpos) + (size_t)chain * 2 * (size_t)(n - n1 + 1) : (gint)nullptr;
+        const gint lin = evp + (n - n1 + 1);
+        const gint anc = a.q2 ? glob(a.anclog) + (size_t)chain * (size_t)(n - n1 + 1) * P : (gint)nullptr;
+        if (nev > 0) {
+            __syncthreads();
+            if (tid == 0) {
+                int cur = pstar;
+                for (int e = nev - 1; e >= 0; --e) { cur = anc[(size_t)e * P + cur]; lin[e] = cur; }
+            }
+            __syncthreads();
+        }
         for (long long pp = tid; pp < n; pp += T) {
             const int i = order[pp];
+            int slot = pstar;
+            if (nev > 0 && pp >= n1 - 1 && (int)pp <= evp[nev - 1]) {
+                int lo = 0, hi = nev - 1;              // first event whose position is >= pp
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (evp[mid] >= (int)pp) hi = mid; else lo = mid + 1; }
+                slot = lin[lo];
+            }
             for (int k = 0; k < K; ++k) {
                 int v;
                 if (pp < n1 - 1) v = s_in[(size_t)k * n + i];   // sstar[:, i, k] .= s[i, k] (:204)
                 else {
                     const unsigned char *ss = (const unsigned char *)(a.ds[k].arena + (size_t)chain * a.ds[k].stride + a.ds[k].o_sstar);
-                    v = ss[(size_t)pp * P + pstar];
+                    v = ss[(size_t)pp * P + slot];
                 }
                 a.s_out[((size_t)chain * K + k) * n + i] = v;
             }

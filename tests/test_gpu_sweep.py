@@ -35,11 +35,11 @@ def test_golden(pkg, case):
     replay(z, data, kinds, lambda d, k, N, P, seed, q1: GpuRunner(pkg, d, k, N, P, seed, q1))
 
 
-def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, block=0, check_state=True):
+def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, block=0, check_state=True, q2=0):
     rng = np.random.default_rng(seed)
     n, K = data[0].shape[0], len(data)
-    g = GpuRunner(pkg, data, kinds, N, P, seed, q1, block_threads=block)
-    o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1)
+    g = GpuRunner(pkg, data, kinds, N, P, seed, q1, block_threads=block, q2_mode=q2)
+    o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1, q2_mode=q2)
     Dcum = np.cumsum([d.shape[1] for d in data])[:-1]
     s = rng.integers(1, N + 1, size=(n, K))
     for it in range(1, iters + 1):
@@ -76,6 +76,24 @@ def test_mixed_types(pkg, O, q1):
     rng = np.random.default_rng(1)
     data, kinds = make_mixed(rng, 300)
     _compare_run(pkg, O, data, kinds, 12, 256, 3, 50 + q1, 75, q1=q1)
+
+
+@pytest.mark.parametrize("P,n,N", [(64, 300, 12), (1024, 200, 8), (300, 150, 6)])
+def test_q2_mode_history_permuted_like___pmdi(pkg, O, P, n, N):
+    """q2_mode = 1: the allocation history follows the ancestors at every resampling (src/__pmdi.jl:285).  The device
+    logs the ancestor tables and traces the selected particle's lineage back at the end; the oracle permutes literally."""
+    rng = np.random.default_rng(4)
+    data, kinds = make_mixed(rng, n)
+    g = _compare_run(pkg, O, data, kinds, N, P, 3, 90 + P, n // 4, q2=1)
+    # ... and it is a different trajectory from pmdi()'s (q2_mode = 0) on the same inputs
+    rng = np.random.default_rng(90 + P)
+    s = rng.integers(1, N + 1, size=(n, 3))
+    order = rng.permutation(n) + 1
+    Pi, Phi = random_hypers(rng, N, 3)
+    a = g.sweep(1, s, order, n // 4, Pi, Phi, None)
+    b = GpuRunner(pkg, data, kinds, N, P, 90 + P, 0).sweep(1, s, order, n // 4, Pi, Phi, None)
+    assert a["stats"]["n_resamples"] == b["stats"]["n_resamples"] > 0 and a["p_star"] == b["p_star"]
+    assert (a["s"] != b["s"]).any()
 
 
 def test_feature_flags(pkg, O):
