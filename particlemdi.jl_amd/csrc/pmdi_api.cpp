@@ -142,7 +142,8 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab;
+    int ksplit = 0;
     bool have_order = false;
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
@@ -210,6 +211,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.cost = (long long *)h->d_cost.p;
     a.work = (long long *)h->d_work.p;
     a.anclog = (int *)h->d_anclog.p; a.evpos = (int *)h->d_evpos.p;
+    a.ksplit = h->ksplit; a.xcnt = (int *)h->d_xcnt.p; a.xinc = (double *)h->d_xinc.p; a.xlab = (int *)h->d_xlab.p;
     a.chain_order = h->have_order ? (const int *)h->d_lorder.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
@@ -223,6 +225,11 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
 {
     const int C = h->cfg.n_chains;
     hipError_t e;
+    if (h->ksplit) {       // arrival counters of the hand-offs; the K workgroups of a chain ADD their counters into stats
+        HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, st));
+        HIP_TRY(hipMemsetAsync(a.stats, 0, (size_t)C * 64, st));
+        HIP_TRY(hipMemsetAsync(a.err, 0, (size_t)C * 4, st));
+    }
     if (!h->split) {
         e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, st);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
@@ -277,7 +284,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -411,6 +418,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         if (2 * N > PMDI_ITEM_CAP) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));
         h->two_per_cu = env_int("PMDI_TWO_PER_CU", 1);
+        // K > 1: one workgroup per (chain, dataset), meeting once per swept observation (pmdi_sweep.hip); the history-permuting
+        // __pmdi mode keeps the single-workgroup form (its ancestor log is per chain)
+        h->ksplit = (K > 1 && cfg->q2_mode == 0 && (long long)K * n < (1LL << 27) && env_int("PMDI_KSPLIT", 1) != 0) ? 1 : 0;
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         // per workgroup width: LDS term buffer (at least P doubles for the resampling weights, the
         // per-wave CDF exchange areas, a few rows of 2*D+1) and which per-particle tables fit LDS
@@ -424,15 +434,35 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             SweepArgs a;
             fill_sweep_common(h, a);
             a.terms_cap = tc; a.pid_lds = 1; a.pp_lds = 1;
-            const size_t lds_target = (size_t)env_int("PMDI_LDS_TARGET", 150 * 1024);
-            if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pid_lds = 0;   // class ids of K*P particles do not fit: global memory
-            if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pp_lds = 0;    // nor does the per-particle step scratch
+            // Two chains per CU (<= 80 KiB each) hide each other's dependent latencies: +40 % aggregate throughput on the
+            // headline workload even with the per-particle tables in global memory.  So: the largest set of per-particle
+            // tables that still fits 80 KiB; if none does, one chain per CU with everything that fits 150 KiB in LDS.
+            const char *tgt = getenv("PMDI_LDS_TARGET");
+            const size_t half = 80 * 1024;
+            bool fits_half = false;
+            if (!tgt) {
+                for (int opt = 0; opt < 3 && !fits_half; ++opt) {
+                    a.pid_lds = opt < 1; a.pp_lds = opt < 2;
+                    fits_half = pmdi_sweep_lds_bytes(a, T) <= half;
+                }
+            }
+            if (!fits_half) {
+                a.pid_lds = 1; a.pp_lds = 1;
+                const size_t lds_target = tgt ? (size_t)atoi(tgt) : (size_t)150 * 1024;
+                if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pid_lds = 0;   // class ids of K*P particles do not fit: global memory
+                if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pp_lds = 0;    // nor does the per-particle step scratch
+            }
             pid_lds = a.pid_lds; pp_lds = a.pp_lds;
             if (pmdi_sweep_lds_bytes(a, T) > 160 * 1024)
                 return fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, T));
             return 0;
         };
         if ((rc = configure(h->T, h->terms_cap, h->pid_lds, h->pp_lds))) return bail(rc);
+        {   // one chain per CU anyway: the 256-register build (no spills) instead of the register-capped one
+            SweepArgs a;
+            fill_sweep_common(h, a);
+            if (!getenv("PMDI_TWO_PER_CU") && pmdi_sweep_lds_bytes(a, h->T) > 80 * 1024) h->two_per_cu = 0;
+        }
         // automatic width: split the chains of a sweep into a heavy and a light launch
         h->split = cfg->block_threads == 0 && h->T > 256 && env_int("PMDI_SPLIT", 1) != 0;
         h->light_ids = env_int("PMDI_LIGHT_IDS", 40);
@@ -454,12 +484,15 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         }
     }
     const int C = cfg->n_chains;
-    if ((rc = h->d_usc.ensure((size_t)C * P * 8)) || (rc = h->d_partstar.ensure((size_t)C * P * 4)) ||
+    if ((rc = h->d_usc.ensure((size_t)C * K * P * 8)) || (rc = h->d_partstar.ensure((size_t)C * K * P * 4)) ||
         (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
         (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
         (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
+        return bail(rc);
+    if (h->ksplit && ((rc = h->d_xcnt.ensure((size_t)C * 32 * 4)) || (rc = h->d_xinc.ensure((size_t)C * 2 * K * P * 8)) ||
+                      (rc = h->d_xlab.ensure((size_t)C * 2 * K * P * 4))))
         return bail(rc);
     if (cfg->q2_mode == 1 &&       // ancestor log of the resampling events: up to one per swept observation
         ((rc = h->d_anclog.ensure((size_t)C * (size_t)n * P * 4)) || (rc = h->d_evpos.ensure((size_t)C * 2 * (size_t)n * 4))))

@@ -101,6 +101,12 @@ struct SweepArgs {
     long long *cost;            // [chain] shader cycles this chain's sweep took (drives the next launch order)
     const int *chain_order;     // [n_chains] workgroup b sweeps chain chain_order[b] (heaviest first), or null
     const unsigned char *group_flag;  // [n_chains] 1 = heavy chain (many private clusters), 0 = light; or null
+    // split mode (K > 1): the K datasets of a chain are swept by K cooperating workgroups that meet once per swept observation
+    int ksplit;                 // 1: one dataset per workgroup, grid = chain slots (padded to 8) x K
+    int n_slots;                // chain slots of this launch
+    int *xcnt;                  // [chain][32] arrival counter of the chain's hand-off (first word; own 128-B line)
+    double *xinc;               // [chain][2][K][P] log-weight increment per particle (by parity of the swept observation)
+    int *xlab;                  // [chain][2][K][P] chosen label per particle
     int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
     int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
 };

@@ -158,6 +158,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     // ---- tables of (class, label) items: a.item_cap entries each (256, or 384 when N > 32 so that more than
     // five classes stay on the fast path); need .. dl are contiguous (the fallback step's cluster list) ----
     const size_t icap = (size_t)a.item_cap;
+    const int KL = a.ksplit ? 1 : a.K;                       // datasets this workgroup sweeps
     c.lpl = take(icap * 8);
     c.cdf = take((2 * icap + 4) * 8);                        // rows of N + 2: CDF, log-increment, one-hot label
     c.need = take(icap * 4);
@@ -171,20 +172,20 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.dl = take((size_t)3 * PMDI_DL_LDS * 4);
     // ---- sizes that depend on the configuration ----
     c.xs = take((size_t)a.Dmax * 8);
-    c.pis = take((size_t)a.K * a.N * 8);
+    c.pis = take((size_t)KL * a.N * 8);
     c.term = take((size_t)a.terms_cap * 8);
     c.lw = take((size_t)a.P * 8);
-    c.pid = take(a.pid_lds ? (size_t)a.K * a.P * 4 : 0);
+    c.pid = take(a.pid_lds ? (size_t)KL * a.P * 4 : 0);
     c.sid = take(a.pp_lds ? (size_t)a.P * 4 : 0);
     c.kv = take(a.pp_lds ? (size_t)a.P * 4 : 0);
     c.lead_of = take((size_t)(a.P + 1) * 4);
     c.slot_of = take((size_t)(a.P + 1) * 4);
-    c.cl_lead = take((size_t)a.K * PMDI_CLS_LDS * 4);
-    c.cl_val = take((size_t)a.K * PMDI_CLS_LDS * 4);
+    c.cl_lead = take((size_t)KL * PMDI_CLS_LDS * 4);
+    c.cl_val = take((size_t)KL * PMDI_CLS_LDS * 4);
     c.bm_fresh = take((size_t)((a.P >> 6) + 1) * 8);
     c.bm_clone = take((size_t)((a.P >> 6) + 1) * 8);
-    c.fl = take((size_t)a.K * Dp);
-    c.news = take((size_t)a.K * a.P);
+    c.fl = take((size_t)KL * Dp);
+    c.news = take((size_t)KL * a.P);
     c.total = o;
 }
 
@@ -204,7 +205,7 @@ struct Sh {
     lu8 fl, news;
 };
 
-enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6, M_FAIL = 7, M_NLEAF = 8, M_NPROG = 9, M_ND = 10, M_MOVED = 11 };
+enum { M_NEED = 0, M_OVF = 1, M_PSTAR = 2, M_NK = 3, M_NF = 4, M_NCLS = 5, M_NCLONE = 6, M_FAIL = 7, M_NLEAF = 8, M_NPROG = 9, M_ND = 10, M_MOVED = 11, M_XAB = 12 };
 
 // class list of dataset k: slot r -> leader particle / class value.  The first cls_lds slots
 // live in LDS, the rest (burn-in only) in global memory.
@@ -280,8 +281,14 @@ __device__ __forceinline__ int rebuild_classes(const Dual<int> &pidk, const ClsL
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                      \
     const SweepArgs &a = *ap;                                                                  \
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                             \
-    const int chain = a.chain_order ? a.chain_order[blockIdx.x] : (int)blockIdx.x;            \
-    const int K = (K1_) ? 1 : a.K, N = a.N, P = a.P, cap = a.cap;                              \
+    /* split mode: the K datasets of a chain are swept by K cooperating workgroups (blocks b, b+8, ... share a chain's \
+       XCD under round-robin placement: speed only, the hand-off is placement-independent) */  \
+    const int Kf = a.K;                                                                        \
+    const int bslot = a.ksplit ? (int)((blockIdx.x / (8u * (unsigned)Kf)) * 8u + (blockIdx.x & 7u)) : (int)blockIdx.x; \
+    const int kd0 = a.ksplit ? (int)((blockIdx.x >> 3) % (unsigned)Kf) : 0;                    \
+    const int chain = bslot < a.n_slots ? (a.chain_order ? a.chain_order[bslot] : bslot) : 0;  \
+    const int K = ((K1_) || a.ksplit) ? 1 : a.K, N = a.N, P = a.P, cap = a.cap;                \
+    const DsetDev *dsb = a.ds + kd0;                                                           \
     const long long n = a.n, n1 = a.n1;                                                        \
     const unsigned long long seed = a.seed + (unsigned long long)chain;                        \
     const unsigned iter = a.iter;                                                              \
@@ -289,14 +296,14 @@ __device__ __forceinline__ int rebuild_classes(const Dual<int> &pidk, const ClsL
     const int H = PMDI_HT_SIZE;                                                                   \
     Sh sh;                                                                                     \
     build_sh(a, smem, sh);                                                                     \
-    const gcint s_in = glob(a.s_in) + (size_t)chain * K * n;                                   \
+    const gcint s_in = glob(a.s_in) + ((size_t)chain * Kf + kd0) * n;                          \
     const gcint order = glob(a.order) + (size_t)chain * n;                                     \
-    const gcdbl Pi = glob(a.Pi) + (size_t)chain * K * N;                                       \
+    const gcdbl Pi = glob(a.Pi) + ((size_t)chain * Kf + kd0) * N;                              \
     const gcdbl logphi = glob(a.logphi) + (size_t)chain * a.npairs;                            \
     const gcu8 flags = a.flags ? glob(a.flags) + (size_t)chain * a.sumD : (gcu8)nullptr;       \
-    const gdbl usc = glob(a.uscratch) + (size_t)chain * P;                                     \
-    const gint pstar_raw = glob(a.partstar) + (size_t)chain * P;                               \
-    (void)lane; (void)wave; (void)cap; (void)n1; (void)seed; (void)iter; (void)Dp; (void)H;    \
+    const gdbl usc = glob(a.uscratch) + ((size_t)chain * Kf + kd0) * P;                        \
+    const gint pstar_raw = glob(a.partstar) + ((size_t)chain * Kf + kd0) * P;                  \
+    (void)lane; (void)wave; (void)cap; (void)n1; (void)seed; (void)iter; (void)Dp; (void)H; (void)dsb; (void)Kf; (void)bslot; \
     (void)s_in; (void)order; (void)Pi; (void)logphi; (void)flags; (void)usc; (void)pstar_raw
 
 __device__ __forceinline__ int opaque_vgpr(int v)
@@ -376,7 +383,7 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
     __syncthreads();
     // ---- reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207) ----
     for (int k = 0; k < K; ++k) {
-        const DsetDev &d = a.ds[k];
+        const DsetDev &d = dsb[k];
         const KS s = make_ks(d, chain);
         const int D = d.D;
         const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
@@ -553,7 +560,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
         }                                                                       \
     } while (0)
     PHS(12);
-    const DsetDev &d = a.ds[k];
+    const DsetDev &d = dsb[k];
     const KS s = make_ks(d, chain);
     const int D = d.D;
     const gint part = s.part[sh.kcur[k]];
@@ -603,7 +610,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                             const int cls = pidk[p];
                             const Dual<double> row = cdfp + (size_t)sh.slot_of[cls] * (N + 2);
                             if (p != 0) {
-                                const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                                const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)(kd0 + k), (unsigned)p, SITE_DRAW);
                                 for (int t = 0; t < N - 1; ++t) {
                                     if (row[ns] > u) break;
                                     ++ns;
@@ -611,7 +618,13 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                             } else {
                                 ns = s_in[(size_t)k * n + i];            // reference trajectory (:262)
                             }
-                            sh.lw[p] += row[N];
+                            if (!a.ksplit) {
+                                sh.lw[p] += row[N];
+                            } else {
+                                const size_t xo = (((size_t)chain * 2 + (size_t)((pos - (n1 - 1)) & 1)) * Kf + kd0) * P + p;
+                                __hip_atomic_store((unsigned long long *)a.xinc + xo, (unsigned long long)__double_as_longlong((double)row[N]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(a.xlab + xo, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                             key = (cls - 1) * N + ns;
                             c = part[ns * P + p];                        // sstar_id (:264)
                             const int v = s.newid[key];
@@ -878,7 +891,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             for (int p = tid; p < P; p += T) sh.lw[p] = 1.0;     // src/pmdi.jl:319
             __syncthreads();
             // ancestor of every slot after the conditional-SMC fix-up (slot 0 keeps particle 0)
-            const Dual<int> ancp = dual(a.pp_lds != 0, sh.kv, make_ks(a.ds[0], chain).kv);
+            const Dual<int> ancp = dual(a.pp_lds != 0, sh.kv, make_ks(dsb[0], chain).kv);
             for (int p = tid; p < P; p += T) ancp[p] = (p == 0) ? 0 : (p <= js ? pstar_raw[p - 1] : pstar_raw[p]);
             __syncthreads();
             if (a.q2) {
@@ -892,7 +905,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             }
             PHR(2);   // search + ancestors
             for (int k = 0; k < K; ++k) {                         // src/pmdi.jl:320-340
-                const DsetDev &d = a.ds[k];
+                const DsetDev &d = dsb[k];
                 const KS s = make_ks(d, chain);
                 const int D = d.D;
                 const int cur = sh.kcur[k];
@@ -1101,31 +1114,43 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
                 int v;
                 if (pp < n1 - 1) v = s_in[(size_t)k * n + i];   // sstar[:, i, k] .= s[i, k] (:204)
                 else {
-                    const unsigned char *ss = (const unsigned char *)(a.ds[k].arena + (size_t)chain * a.ds[k].stride + a.ds[k].o_sstar);
+                    const unsigned char *ss = (const unsigned char *)(dsb[k].arena + (size_t)chain * dsb[k].stride + dsb[k].o_sstar);
                     v = ss[(size_t)pp * P + slot];
                 }
-                a.s_out[((size_t)chain * K + k) * n + i] = v;
+                a.s_out[((size_t)chain * Kf + kd0 + k) * n + i] = v;
             }
         }
-        if (a.lw_out) for (int p = tid; p < P; p += T) a.lw_out[(size_t)chain * P + p] = sh.lw[p];
+        if (a.lw_out && kd0 == 0) for (int p = tid; p < P; p += T) a.lw_out[(size_t)chain * P + p] = sh.lw[p];
         if (a.pid_lds)   // debug export reads the class ids from global memory
             for (int k = 0; k < K; ++k) {
-                int *gp = (int *)(a.ds[k].arena + (size_t)chain * a.ds[k].stride + a.ds[k].o_pid);
+                int *gp = (int *)(dsb[k].arena + (size_t)chain * dsb[k].stride + dsb[k].o_pid);
                 for (int p = tid; p < P; p += T) gp[p] = sh.pid[(size_t)k * P + p];
             }
         if (tid < K) {
-            a.kstate[((size_t)chain * PMDI_KMAX_I + tid) * 2] = sh.kmaxid[tid];
-            a.kstate[((size_t)chain * PMDI_KMAX_I + tid) * 2 + 1] = sh.kcur[tid];
+            a.kstate[((size_t)chain * PMDI_KMAX_I + kd0 + tid) * 2] = sh.kmaxid[tid];
+            a.kstate[((size_t)chain * PMDI_KMAX_I + kd0 + tid) * 2 + 1] = sh.kcur[tid];
         }
         if (tid == 0) {
-            a.pstar[chain] = pstar;
             long long *st = a.stats + (size_t)chain * 8;
-            st[ST_NOPS] = sh.stat[0]; st[ST_NRESAMPLE] = sh.stat[1]; st[ST_NCLONES] = sh.stat[2];
-            st[ST_MAXID] = sh.stat[3]; st[ST_SUMCLASSES] = sh.stat[4];
-            st[5] = sh.stat[5]; st[6] = sh.stat[6]; st[7] = sh.stat[7];
-            a.err[chain] = 0;
+            if (!a.ksplit) {
+                a.pstar[chain] = pstar;
+                st[ST_NOPS] = sh.stat[0]; st[ST_NRESAMPLE] = sh.stat[1]; st[ST_NCLONES] = sh.stat[2];
+                st[ST_MAXID] = sh.stat[3]; st[ST_SUMCLASSES] = sh.stat[4];
+                st[5] = sh.stat[5]; st[6] = sh.stat[6]; st[7] = sh.stat[7];
+                a.err[chain] = 0;
+            } else {
+                // the K workgroups of the chain add their datasets' counters (the host zeroed stats and err before the launch)
+                if (kd0 == 0) { a.pstar[chain] = pstar; st[ST_NRESAMPLE] = sh.stat[1]; }
+                atomicAdd((unsigned long long *)&st[ST_NOPS], (unsigned long long)sh.stat[0]);
+                atomicAdd((unsigned long long *)&st[ST_NCLONES], (unsigned long long)sh.stat[2]);
+                atomicMax((unsigned long long *)&st[ST_MAXID], (unsigned long long)sh.stat[3]);
+                atomicAdd((unsigned long long *)&st[ST_SUMCLASSES], (unsigned long long)sh.stat[4]);
+                atomicAdd((unsigned long long *)&st[5], (unsigned long long)sh.stat[5]);
+                atomicAdd((unsigned long long *)&st[6], (unsigned long long)sh.stat[6]);
+                atomicAdd((unsigned long long *)&st[7], (unsigned long long)sh.stat[7]);
+            }
         }
-        if (a.work && tid < PMDI_KMAX_I * 8) a.work[(size_t)chain * PMDI_KMAX_I * 8 + tid] = sh.wk[tid];
+        if (a.work && tid < K * 8) a.work[((size_t)chain * PMDI_KMAX_I + kd0) * 8 + tid] = sh.wk[tid];
     }
 }
 
@@ -1138,8 +1163,15 @@ template <int T, int WPS, bool K1>
 __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__restrict__ ap)
 {
     PMDI_PREAMBLE_K(K1);
+    if (bslot >= a.n_slots) return;            // padding of a split launch (chain slots are dealt in groups of eight)
     // two launches share the chains of a sweep (heavy: wide workgroups, light: narrow ones)
-    if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || (int)blockIdx.x < a.rank_lo || (int)blockIdx.x >= a.rank_hi)) return;
+    if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || bslot < a.rank_lo || bslot >= a.rank_hi)) return;
+    // hand-off area of the split mode: per (chain, parity of the swept observation, dataset): the log-weight increment and
+    // the chosen label of every particle; one arrival counter per chain
+    // (the addresses are rebuilt from the argument block where they are used: nothing of this stays live across the step loop)
+#define XSPLIT (a.ksplit != 0)
+#define XCNT (glob(a.xcnt) + (size_t)chain * 32)
+#define XOFF(par_, kd_) ((((size_t)chain * 2 + (size_t)(par_)) * (size_t)a.K + (size_t)(kd_)) * (size_t)a.P)
 
     const long long t_start = clock64();
 #ifdef PMDI_RESAMPLE_TIMERS
@@ -1180,7 +1212,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     int nxi = 0;
     int ns0_next = s_in[i_next];   // ... and the reference trajectory's label there (dataset 0)
     {
-        const DsetDev &d0 = a.ds[0];
+        const DsetDev &d0 = dsb[0];
         if (tid < d0.D) {
             if (d0.kind == K_GAUSSIAN) nx = glob(d0.xf)[(size_t)i_next * d0.D + tid]; else nxi = glob(d0.xi)[(size_t)i_next * d0.D + tid];
         }
@@ -1195,7 +1227,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             {
             int tid = opaque_vgpr(tid_outer_), lane = opaque_vgpr(lane_outer_);
 #define FRESH_LANE_IDS() asm volatile("" : "+v"(tid), "+v"(lane))
-            const DsetDev &d = a.ds[k];
+            const DsetDev &d = dsb[k];
             const KS s = make_ks(d, chain);
             const int D = d.D;
             const int maxid = sh.kmaxid[k];
@@ -1405,7 +1437,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 int kn = k + 1, in_ = i;
                 bool have = true;
                 if (kn == K) { kn = 0; in_ = i_next; have = pos + 1 < n; }
-                const DsetDev &dn = a.ds[kn];
+                const DsetDev &dn = dsb[kn];
                 if (have && tid < dn.D) {
                     if (dn.kind == K_GAUSSIAN) nx = glob(dn.xf)[(size_t)in_ * dn.D + tid]; else nxi = glob(dn.xi)[(size_t)in_ * dn.D + tid];
                 }
@@ -1449,7 +1481,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         } else if (hot >= 0) {
                             ns = hot;                                // one-hot CDF: no random number needed
                         } else if (p < P) {
-                            const double u01 = uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                            const double u01 = uniform01(seed, iter, (unsigned)pos, (unsigned)(kd0 + k), (unsigned)p, SITE_DRAW);
                             // first label whose CDF exceeds u (:252-260); the CDF is non-decreasing, so
                             // that is the number of leading entries that do not exceed u
                             int t = 0;
@@ -1466,7 +1498,13 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     for (int u = 0; u < 4; ++u) {
                         const int p = pb0 + u * T + tid;
                         if (p < P) {
-                            sh.lw[p] = lw_[u] + inc_[u];
+                            if (!XSPLIT) {
+                                sh.lw[p] = lw_[u] + inc_[u];
+                            } else {        // the increments of the K datasets are added in dataset order after the hand-off
+                                const size_t xo = XOFF((pos - (n1 - 1)) & 1, kd0) + p;
+                                __hip_atomic_store((unsigned long long *)a.xinc + xo, (unsigned long long)__double_as_longlong(inc_[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(a.xlab + xo, ns_[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                             sh.news[k * P + p] = (unsigned char)ns_[u];
                             s.sstar[(size_t)pos * P + p] = (unsigned char)ns_[u];   // (:265)
                             sidp[p] = r_[u] * N + ns_[u];
@@ -1688,7 +1726,52 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 
         // -- Phi_upweight! (src/misc.jl:50-59)
         PH(9);
-        if (K > 1) {
+        if (XSPLIT) {
+            // Hand-off between the K workgroups of the chain (one per swept observation): every workgroup has stored its dataset's
+            // records with agent-scope (sc1, write-through) stores; each storing wave drains them, the workgroup meets, one lane
+            // adds to the chain's arrival counter and polls it with sc1 loads; after the workgroup barrier every lane reads the
+            // K records of its particles with sc1 loads (they bypass the CU's L1, which another CU's stores never refresh).
+            // MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": placement-independent.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(gen(XCNT), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int target = Kf * (int)(pos - (n1 - 1) + 1);
+                const long long w0 = wall_clock64();
+                int ab = 0;
+                for (;;) {
+                    const int v = __hip_atomic_load(gen(XCNT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v >= (1 << 28)) { ab = 2; break; }                    // a partner failed (pool capacity): stop with it
+                    if (v >= target) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - w0 > 2000000000LL) { ab = 3; break; } // 20 s at 100 MHz: a partner never arrived
+                }
+                sh.misc[M_XAB] = ab;
+            }
+            __syncthreads();
+            if (sh.misc[M_XAB]) { failed = sh.misc[M_XAB]; break; }
+            const unsigned long long *xi = (const unsigned long long *)a.xinc + XOFF((pos - (n1 - 1)) & 1, 0);
+            const int *xl = a.xlab + XOFF((pos - (n1 - 1)) & 1, 0);
+            for (int p = tid; p < P; p += T) {
+                unsigned long long labs = 0;                                   // the K chosen labels, a byte each (N <= 64)
+                double w = sh.lw[p];
+                for (int kk = 0; kk < Kf; ++kk) {                              // logweight[p] += increment, in dataset order (:227,:245)
+                    const unsigned long long bits = __hip_atomic_load(xi + (size_t)kk * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int lb = __hip_atomic_load(xl + (size_t)kk * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    labs |= (unsigned long long)(lb & 0xff) << (8 * kk);
+                    w = w + __longlong_as_double((long long)bits);
+                }
+                int pr = 0;
+                for (int k1 = 0; k1 < Kf - 1; ++k1)
+                    for (int k2 = k1 + 1; k2 < Kf; ++k2) {
+                        w += (((labs >> (8 * k1)) & 0xff) == ((labs >> (8 * k2)) & 0xff)) ? logphi[pr] : 0.0;
+                        ++pr;
+                    }
+                sh.lw[p] = w;
+            }
+            lw_uniform = false;
+            __syncthreads();
+        } else if (K > 1) {
             for (int p = tid; p < P; p += T) {
                 int pr = 0;
                 double w = sh.lw[p];
@@ -1728,27 +1811,31 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         }
 
         if (a.trace_on && tid == 0) {
-            double *tr = a.trace + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
-            tr[0] = ess;
-            tr[1] = resample ? 1.0 : 0.0;
-            for (int k = 0; k < K; ++k) { tr[2 + k] = (double)sh.kmaxid[k]; tr[2 + K + k] = (double)sh.kncls[k]; }
+            double *tr = a.trace + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * Kf);
+            if (kd0 == 0) { tr[0] = ess; tr[1] = resample ? 1.0 : 0.0; }
+            for (int k = 0; k < K; ++k) { tr[2 + kd0 + k] = (double)sh.kmaxid[k]; tr[2 + Kf + kd0 + k] = (double)sh.kncls[k]; }
         }
     }
 
     if (failed) {
-        if (tid == 0) { a.err[chain] = -4; a.cost[chain] = clock64() - t_start; }  // PMDI_E_POOL
+        if (tid == 0) {
+            if (failed == 1) a.err[chain] = -4;                                     // PMDI_E_POOL
+            else if (failed == 3) a.err[chain] = -6;                                // a partner workgroup never arrived
+            a.cost[chain] = clock64() - t_start;
+            if (XSPLIT) __hip_atomic_fetch_add(gen(XCNT), 1 << 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // partners stop waiting
+        }
         return;
     }
 
     PH(11);
     sweep_final<T>(ap);
     PH(12);
-    if (tid == 0) a.cost[chain] = clock64() - t_start;
+    if (tid == 0 && kd0 == 0) a.cost[chain] = clock64() - t_start;
     if (a.phase && tid == 0) {
         sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0;
     }
     __syncthreads();
-    if (a.phase && tid < 16) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
+    if (a.phase && tid < 16 && kd0 == 0) a.phase[(size_t)chain * 16 + tid] = sh.ph[tid];
 #ifdef PMDI_RESAMPLE_TIMERS
     __syncthreads();
     if (a.phase && tid < 10) a.phase[(size_t)chain * 16 + tid] = sh.stat[8 + tid];   // A/B build: resampling sub-phases instead
@@ -1794,12 +1881,14 @@ size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T)
     return c.total;
 }
 
-hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t stream)
+hipError_t pmdi_launch_sweep(const SweepArgs &a_in, SweepArgs *d_args, int n_chains, int T, hipStream_t stream)
 {
+    SweepArgs a = a_in;
+    a.n_slots = n_chains;
     const size_t lds = pmdi_sweep_lds_bytes(a, T);
     const bool two = a.two_per_cu != 0;
     const void *fn = nullptr;
-    const bool k1 = a.K == 1;
+    const bool k1 = a.K == 1 || a.ksplit;      // one dataset per workgroup
     if (T == 1024) fn = k1 ? (const void *)pmdi_sweep_kernel<1024, 4, true> : (const void *)pmdi_sweep_kernel<1024, 4, false>;
     else if (T == 512 && two) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 4, true> : (const void *)pmdi_sweep_kernel<512, 4, false>;
     else if (T == 512) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 2, true> : (const void *)pmdi_sweep_kernel<512, 2, false>;
@@ -1814,7 +1903,10 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
     if (e != hipSuccess) return e;
     const SweepArgs *ap = d_args;
     void *args[] = {(void *)&ap};
-    e = hipLaunchKernel(fn, dim3(n_chains), dim3(T), args, lds, stream);
+    // split mode: K workgroups per chain slot, slots dealt in groups of eight so that blocks b, b + 8, ... (one XCD
+    // under round-robin placement) belong to one chain
+    const unsigned grid = a.ksplit ? (unsigned)((n_chains + 7) / 8) * 8u * (unsigned)a.K : (unsigned)n_chains;
+    e = hipLaunchKernel(fn, dim3(grid), dim3(T), args, lds, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
