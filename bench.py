@@ -10,6 +10,10 @@ the C ABI (pmdi_gibbs_step): shuffle + hyper-parameter updates (one kernel), the
 persistent kernel per launch group, one workgroup per chain), feature selection when the config has it, label
 alignment (one kernel).  Inputs are resident: nothing crosses PCIe inside the timed region.
 
+Two forms of the sweep for K > 1 (include/pmdi_hip.h, PMDI_KSPLIT): one workgroup per chain (throughput form: what `value`
+is measured with, the GPU filled with chains) and K cooperating workgroups per chain (latency form: a chain's sweep is ~2.2x
+shorter; measured in the same run on a subset of the settled chains and reported as `latency_form`).
+
 Protocol (state-independent by construction -- the cost of a sweep depends on how settled the chains are):
   1. `--burnin B` iterations from the random start of src/pmdi.jl:59-66, timed separately (`burnin_iters_per_sec`:
      what a user sees for the first B iterations);  B is a property of the workload, NOT of --warmup;
@@ -45,7 +49,7 @@ DESCR = {
     "cfg5": "cfg5: 3 x Gaussian 20000x200, K=3, N=50, P=4096, rho=0.25, featureSelect on",
 }
 # chains per GPU (one workgroup each) and burn-in iterations per workload
-DEFAULTS = {"HL": (512, 12), "cfg2": (2048, 30), "cfg3": (512, 12), "cfg4": (256, 6), "cfg5": (256, 3)}
+DEFAULTS = {"HL": (1024, 20), "cfg2": (2048, 30), "cfg3": (1024, 12), "cfg4": (256, 6), "cfg5": (256, 3)}
 
 
 def algorithmic_bytes(w, P, n, n1, work, stats):
@@ -154,6 +158,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n of the workload (debug only)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-latency-form", action="store_true", help="skip the split-form leg (K > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -278,7 +283,8 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": DESCR[args.workload] if args.scale == 1.0 else f"{args.workload} scaled n={n}",
                        "chains_per_gpu": C, "burnin_iterations": burnin,
-                       "block_threads": sw.block_threads, "lds_bytes_per_chain": sw.lds_bytes,
+                       "block_threads": sw.block_threads, "lds_bytes_per_workgroup": sw.lds_bytes,
+                       "workgroups_per_chain": (K if sw.split else 1),
                        "swept_obs_per_iter": n_s, "parallelism": f"chains x{world}",
                        "host_side": "none inside an iteration: hypers, shuffle, sweep, label alignment are device kernels (pmdi_gibbs_step)"},
             "obs_particles_per_sec": total_iters * n_s * P / dt,
@@ -307,6 +313,36 @@ def main():
         comm.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and K > 1 and not args.no_latency_form and not sw.split:
+        # ---- the latency form on settled chains of this run: K cooperating workgroups per chain, as many chains as are resident at once
+        order_c = np.argsort(costs)
+        C2 = max(1, min(C, 512 // K))
+        picks = [int(order_c[int(q * (C - 1) / max(C2 - 1, 1))]) for q in range(C2)]          # across the cost range
+        os.environ["PMDI_KSPLIT"] = "1"
+        sw2 = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=C2, seed=seed + (1 << 20), device=local_rank, block_threads=args.block)
+        del os.environ["PMDI_KSPLIT"]
+        g2 = pkg.Gibbs(sw2, rho=w["rho"], feature_select=(args.workload == "cfg5"))
+        for j, c in enumerate(picks):
+            st = g.get(c)
+            g2.set(j, M=st["M"], gamma=st["gamma"], gamma0=st["gamma0"], Phi=st["Phi"], v=st["v"], Z=st["Z"], s=st["s"], order=st["order"], flags=st["flags"])
+        lat_ms = []
+        for it in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g2.step(pkg.STEP_BEGIN, sp); g2.step(pkg.STEP_HYPERS, sp)
+            e0.record(stream); g2.step(pkg.STEP_SWEEP, sp); e1.record(stream)
+            g2.step(pkg.STEP_ALIGN, sp)
+            torch.cuda.synchronize()
+            if it >= 2:
+                lat_ms.append(e0.elapsed_time(e1))
+        g2.results()
+        c2 = sw2.chain_costs().astype(np.float64) / float(sw2.clock_hz)
+        out["latency_form"] = {"split": bool(sw2.split), "chains": C2, "workgroups_per_chain": K, "sweep_kernel_ms": float(np.mean(lat_ms)),
+                               "per_chain_iters_per_sec": {"p50": float(1.0 / np.median(c2)), "slowest": float(1.0 / c2.max()), "fastest": float(1.0 / c2.min())},
+                               "aggregate_sweep_only_iters_per_sec": C2 / (float(np.mean(lat_ms)) * 1e-3),
+                               "handoffs_per_iteration": n_s,
+                               "note": "K cooperating workgroups per chain (one per dataset), one sc1 hand-off per swept observation; "
+                                       "same settled chains as the throughput run, 3 timed iterations after 2"}
+        g2.close(); sw2.close()
     if rank == 0:
         print(f"[bench] GPU part done: {out['value']:.1f} iters/s", file=sys.stderr, flush=True)
         if not args.no_cpu:

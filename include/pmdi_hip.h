@@ -99,7 +99,11 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
  *   PMDI_HEAVY_T          workgroup width of the heavy group (512 or 1024)
  *   PMDI_TWO_PER_CU=0     256-register builds everywhere (one wide chain per CU)
  *   PMDI_TERMS_CAP        LDS doubles for the per-feature terms
- *   PMDI_PHASE_TIMERS=1   per-stage shader-clock timers (pmdi_phase_timers) */
+ *   PMDI_PHASE_TIMERS=1   per-stage shader-clock timers (pmdi_phase_timers)
+ *   PMDI_KSPLIT=0/1       K > 1: one workgroup per chain (throughput form) / K cooperating workgroups per chain, one per
+ *                         dataset, meeting once per swept observation (latency form).  Default: split while n_chains * K
+ *                         workgroups are resident at once.  pmdi_is_split() tells which form a handle uses.
+ *   PMDI_LDS_TARGET       LDS bytes per workgroup above which the per-particle tables move to global memory */
 int pmdi_destroy(pmdi_handle *h);
 const char *pmdi_last_error(void);
 int pmdi_abi_version(void);
@@ -304,6 +308,7 @@ int pmdi_work_counters(pmdi_handle *h, int64_t *out);
 
 int pmdi_sum_D(const pmdi_handle *h);
 int pmdi_block_threads(const pmdi_handle *h);   /* threads per chain workgroup */
+int pmdi_is_split(const pmdi_handle *h);        /* 1: K cooperating workgroups per chain (one per dataset) */
 int64_t pmdi_shader_clock_hz(const pmdi_handle *h); /* the clock pmdi_chain_costs counts in (hipDeviceAttributeClockRate) */
 int64_t pmdi_lds_bytes(const pmdi_handle *h);    /* LDS bytes per chain workgroup */
 int64_t pmdi_pool_cap(const pmdi_handle *h);

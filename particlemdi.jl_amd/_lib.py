@@ -32,7 +32,7 @@ EXPORTS = [
     "pmdi_gibbs_create", "pmdi_gibbs_destroy", "pmdi_gibbs_iterate", "pmdi_gibbs_step", "pmdi_gibbs_iterations",
     "pmdi_gibbs_get", "pmdi_gibbs_set", "pmdi_gibbs_results", "pmdi_gibbs_device_view", "pmdi_gibbs_pack_samples",
     "pmdi_csv_open", "pmdi_csv_write_row", "pmdi_csv_write_gibbs", "pmdi_csv_open_features", "pmdi_csv_write_flags",
-    "pmdi_csv_close", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz",
+    "pmdi_csv_close", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz", "pmdi_is_split",
     "pmdi_comm_unique_id", "pmdi_comm_init_rank", "pmdi_comm_init_all", "pmdi_comm_destroy", "pmdi_comm_rank", "pmdi_comm_size",
     "pmdi_allgather_samples",
 ]
@@ -171,6 +171,7 @@ def lib():
     L.pmdi_comm_size.argtypes = [vp]
     L.pmdi_allgather_samples.restype = C.c_int
     L.pmdi_allgather_samples.argtypes = [vp, i32, vp, vp, i64, vp]
+    L.pmdi_is_split.argtypes = [vp]
     L.pmdi_shader_clock_hz.restype = i64
     L.pmdi_shader_clock_hz.argtypes = [vp]
     L.pmdi_work_counters.restype = C.c_int
@@ -263,6 +264,7 @@ class Sweeper:
         self.block_threads = L.pmdi_block_threads(h)
         self.lds_bytes = L.pmdi_lds_bytes(h)
         self.clock_hz = L.pmdi_shader_clock_hz(h)
+        self.split = bool(L.pmdi_is_split(h))
         self.npairs = max(1, self.K * (self.K - 1) // 2)
         self._keep = None  # the library copied the data
 

@@ -142,7 +142,7 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
     int ksplit = 0;
     bool have_order = false;
     // feature selection
@@ -211,7 +211,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.cost = (long long *)h->d_cost.p;
     a.work = (long long *)h->d_work.p;
     a.anclog = (int *)h->d_anclog.p; a.evpos = (int *)h->d_evpos.p;
-    a.ksplit = h->ksplit; a.xcnt = (int *)h->d_xcnt.p; a.xinc = (double *)h->d_xinc.p; a.xlab = (int *)h->d_xlab.p;
+    a.ksplit = h->ksplit; a.xcnt = (int *)h->d_xcnt.p; a.xinc = (double *)h->d_xinc.p; a.xlab = (int *)h->d_xlab.p; a.xhdr = (unsigned long long *)h->d_xhdr.p;
     a.chain_order = h->have_order ? (const int *)h->d_lorder.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
@@ -284,7 +284,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -418,9 +418,16 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         if (2 * N > PMDI_ITEM_CAP) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));
         h->two_per_cu = env_int("PMDI_TWO_PER_CU", 1);
-        // K > 1: one workgroup per (chain, dataset), meeting once per swept observation (pmdi_sweep.hip); the history-permuting
-        // __pmdi mode keeps the single-workgroup form (its ancestor log is per chain)
-        h->ksplit = (K > 1 && cfg->q2_mode == 0 && (long long)K * n < (1LL << 27) && env_int("PMDI_KSPLIT", 1) != 0) ? 1 : 0;
+        // K > 1: one workgroup per (chain, dataset), meeting once per swept observation (pmdi_sweep.hip): 2.2x shorter sweeps per
+        // chain, but the partners repeat the per-observation serial work (weights, ESS, resampling indices), so when the chains alone
+        // can fill the GPU twice over the single-workgroup form has the higher aggregate throughput.  Default: split while
+        // n_chains * K workgroups fit the device at once (two 512-thread workgroups per CU); PMDI_KSPLIT=0/1 forces either form.
+        // The history-permuting __pmdi mode keeps the single-workgroup form (its ancestor log is per chain).
+        {
+            const int slots = 2 * prop.multiProcessorCount;
+            const int dflt = ((long long)cfg->n_chains * K <= slots) ? 1 : 0;
+            h->ksplit = (K > 1 && cfg->q2_mode == 0 && (long long)K * n < (1LL << 27) && env_int("PMDI_KSPLIT", dflt) != 0) ? 1 : 0;
+        }
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         // per workgroup width: LDS term buffer (at least P doubles for the resampling weights, the
         // per-wave CDF exchange areas, a few rows of 2*D+1) and which per-particle tables fit LDS
@@ -492,7 +499,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
         return bail(rc);
     if (h->ksplit && ((rc = h->d_xcnt.ensure((size_t)C * 32 * 4)) || (rc = h->d_xinc.ensure((size_t)C * 2 * K * P * 8)) ||
-                      (rc = h->d_xlab.ensure((size_t)C * 2 * K * P * 4))))
+                      (rc = h->d_xlab.ensure((size_t)C * 2 * K * P * 4)) || (rc = h->d_xhdr.ensure((size_t)C * 2 * K * 16))))
         return bail(rc);
     if (cfg->q2_mode == 1 &&       // ancestor log of the resampling events: up to one per swept observation
         ((rc = h->d_anclog.ensure((size_t)C * (size_t)n * P * 4)) || (rc = h->d_evpos.ensure((size_t)C * 2 * (size_t)n * 4))))
@@ -559,6 +566,7 @@ int pmdi_work_counters(pmdi_handle *h, int64_t *out)
     return PMDI_OK;
 }
 int pmdi_block_threads(const pmdi_handle *h) { return h ? h->T : 0; }
+int pmdi_is_split(const pmdi_handle *h) { return h ? h->ksplit : 0; }
 int64_t pmdi_shader_clock_hz(const pmdi_handle *h)
 {
     if (!h) return 0;

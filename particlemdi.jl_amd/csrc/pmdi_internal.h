@@ -107,6 +107,7 @@ struct SweepArgs {
     int *xcnt;                  // [chain][32] arrival counter of the chain's hand-off (first word; own 128-B line)
     double *xinc;               // [chain][2][K][P] log-weight increment per particle (by parity of the swept observation)
     int *xlab;                  // [chain][2][K][P] chosen label per particle
+    unsigned long long *xhdr;   // [chain][2][K][2] per-step header: flags / labels, increment of class slot 0
     int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
     int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
 };

@@ -1218,6 +1218,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         }
     }
     for (long long pos = n1 - 1; pos < n && !failed; ++pos) {
+        int xhdr = 0;          // split mode: this step's hand-off is its header alone (bit 0), its one-hot label (bits 8..15)
         const int i = i_next;
         if (pos + 1 < n) i_next = order[pos + 1];
         for (int k = 0; k < K && !failed; ++k) {
@@ -1460,6 +1461,10 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 const int c0 = part[(size_t)ns0 * P];
                 int same = (ncls == 1) ? 1 : 0;
                 const bool one = ncls == 1;                                  // every particle reads CDF row 0
+                // split mode, one class with a one-hot CDF row: every particle gets the same increment, particle 0 the reference
+                // label and all others the one-hot label -- the hand-off is a 16-byte header, no per-particle records
+                const bool hdr_only = XSPLIT && one && (int)sh.cdf[N + 1] >= 0;
+                if (hdr_only) xhdr = 1 | ((int)sh.cdf[N + 1] << 8);
                 for (int pb0 = 0; pb0 < P; pb0 += 4 * T) {       // four particles per lane, stage by stage: their
                     int ns_[4], c_[4], r_[4];                    // LDS chains and pool reads overlap
                     double inc_[4], lw_[4];
@@ -1500,7 +1505,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         if (p < P) {
                             if (!XSPLIT) {
                                 sh.lw[p] = lw_[u] + inc_[u];
-                            } else {        // the increments of the K datasets are added in dataset order after the hand-off
+                            } else if (!hdr_only) {        // the increments of the K datasets are added in dataset order after the hand-off
                                 const size_t xo = XOFF((pos - (n1 - 1)) & 1, kd0) + p;
                                 __hip_atomic_store((unsigned long long *)a.xinc + xo, (unsigned long long)__double_as_longlong(inc_[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 __hip_atomic_store(a.xlab + xo, ns_[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1732,6 +1737,12 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // adds to the chain's arrival counter and polls it with sc1 loads; after the workgroup barrier every lane reads the
             // K records of its particles with sc1 loads (they bypass the CU's L1, which another CU's stores never refresh).
             // MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": placement-independent.
+            if (tid == 0) {        // header: {header-only flag | one-hot label << 8 | reference label << 16, increment of class slot 0}
+                unsigned long long *hd = (unsigned long long *)a.xhdr + ((((size_t)chain * 2 + (size_t)((pos - (n1 - 1)) & 1)) * (size_t)a.K + (size_t)kd0) * 2);
+                const unsigned long long w0 = (unsigned long long)(unsigned)(xhdr | ((int)sh.news[0] << 16));
+                __hip_atomic_store(hd, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(hd + 1, (unsigned long long)__double_as_longlong((double)sh.cdf[N]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
@@ -1752,14 +1763,39 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             if (sh.misc[M_XAB]) { failed = sh.misc[M_XAB]; break; }
             const unsigned long long *xi = (const unsigned long long *)a.xinc + XOFF((pos - (n1 - 1)) & 1, 0);
             const int *xl = a.xlab + XOFF((pos - (n1 - 1)) & 1, 0);
+            const unsigned long long *xh = (const unsigned long long *)a.xhdr + (((size_t)chain * 2 + (size_t)((pos - (n1 - 1)) & 1)) * (size_t)a.K) * 2;
+            PH(12);
+            // the K headers first, all loads in flight together (they are the same addresses for every lane)
+            unsigned hw[PMDI_KMAX_I];
+            unsigned long long hinc[PMDI_KMAX_I];
+#pragma unroll
+            for (int kk = 0; kk < PMDI_KMAX_I; ++kk) {
+                hw[kk] = 0; hinc[kk] = 0;
+                if (kk < Kf) {
+                    hw[kk] = (unsigned)__hip_atomic_load(xh + 2 * kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hinc[kk] = __hip_atomic_load(xh + 2 * kk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
             for (int p = tid; p < P; p += T) {
                 unsigned long long labs = 0;                                   // the K chosen labels, a byte each (N <= 64)
                 double w = sh.lw[p];
-                for (int kk = 0; kk < Kf; ++kk) {                              // logweight[p] += increment, in dataset order (:227,:245)
-                    const unsigned long long bits = __hip_atomic_load(xi + (size_t)kk * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const int lb = __hip_atomic_load(xl + (size_t)kk * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    labs |= (unsigned long long)(lb & 0xff) << (8 * kk);
-                    w = w + __longlong_as_double((long long)bits);
+                unsigned long long rinc[PMDI_KMAX_I];
+                int rlab[PMDI_KMAX_I];
+#pragma unroll
+                for (int kk = 0; kk < PMDI_KMAX_I; ++kk) {                     // per-particle records of the datasets that sent them
+                    rinc[kk] = hinc[kk];
+                    rlab[kk] = (p == 0) ? (int)((hw[kk] >> 16) & 0xffu) : (int)((hw[kk] >> 8) & 0xffu);
+                    if (kk < Kf && !(hw[kk] & 1u)) {
+                        rinc[kk] = __hip_atomic_load(xi + (size_t)kk * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        rlab[kk] = __hip_atomic_load(xl + (size_t)kk * P + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < PMDI_KMAX_I; ++kk) {                     // logweight[p] += increment, in dataset order (:227,:245)
+                    if (kk < Kf) {
+                        labs |= (unsigned long long)(rlab[kk] & 0xff) << (8 * kk);
+                        w = w + __longlong_as_double((long long)rinc[kk]);
+                    }
                 }
                 int pr = 0;
                 for (int k1 = 0; k1 < Kf - 1; ++k1)

@@ -1,28 +1,23 @@
-"""Per-phase shader-clock distribution of the sweep kernel (lane 0 of chain 0)."""
-import os, sys, time
-os.environ["PMDI_PHASE_TIMERS"] = "1"
-import numpy as np, torch
+"""Per-phase shader-clock totals (lane 0 of the chain's workgroup 0) of the last sweep of a few chains.
+usage: PMDI_PHASE_TIMERS=1 python scripts/phase_profile.py WORKLOAD CHAINS ITERS"""
+import os, sys
+import numpy as np
+os.environ.setdefault("PMDI_PHASE_TIMERS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G
 G.build(); pkg = G.load_package()
 from particlemdi_jl_amd import workloads
-from particlemdi_jl_amd.batched import DeviceGibbsK1
-chains = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-warm = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-block = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-scale = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
-w = workloads.make("cfg2", scale)
-g = DeviceGibbsK1(w["data"][0], "gaussian", w["N"], w["P"], chains, seed=1000, block_threads=block)
-names = ["setup+prefix", "stage+needlist", "terms", "sums", "cdf", "C:draw+census", "D1:keys+firsts", "D2:ranks", "E:apply+stats", "phi+ess+looptop", "resample", "final", "slow:draw/census", "slow:stats|unanimous"]
-for it in range(warm + 3):
-    t0 = time.perf_counter(); g.iteration(); st = g.check(); dt = time.perf_counter() - t0
-    ids = st[:, 0] / (g.n - g.n1 + 1)
-    sel = 0
-    if len(sys.argv) > 5: sel = int(np.argmax(ids)) if sys.argv[5] == "max" else int(np.argsort(ids)[len(ids) // 2])
-    ph = g.sw.phase_timers(sel).astype(np.float64)
-    clk_total, rt_total = ph[14], ph[15]
-    ph = ph[:14]
-    tot = ph.sum()
-    n_s = g.n - g.n1 + 1
-    print(f"it {it} chain {sel} ids {ids[sel]:.0f} fast/conv/slow {st[sel,5]}/{st[sel,6]}/{st[sel,7]}: wall {dt*1e3:8.1f} ms  ids/step {st[:,0].mean()/n_s:7.1f} cls/step {st[:,4].mean()/n_s:5.2f} resamp {st[:,1].mean():5.1f} clones {st[:,2].mean():7.1f} | "
-          + " ".join(f"{nm}={100*v/tot:.1f}%" for nm, v in zip(names, ph) if v > 0.004 * tot) + f" | cycles/step {tot/n_s:.0f} | shader clk {clk_total/max(rt_total,1)*100:.0f} MHz (memtime {clk_total:.3g}, realtime ticks {rt_total:.3g})", flush=True)
+name, C, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+w = workloads.make(name)
+sw = pkg.Sweeper(w["data"], w["kinds"], w["N"], w["P"], n_chains=C, seed=41)
+g = pkg.Gibbs(sw, rho=0.25, feature_select=(name == "cfg5"))
+g.iterate(iters); st = g.results()["stats"]
+ns = (w["n"] - g.n1 + 1)
+names = ["0 prefix", "1 looptop/needlist", "2 terms", "3 ordered sum", "4 cdf", "5 draw+vote", "6 keys/firsts", "7 ranks", "8 apply+stats", "9 phi/handoff/ess",
+         "10 resample", "11 final", "12 slow:front", "13 stats update", "14 total cycles", "15 wall ticks"]
+for c in range(min(C, 4)):
+    ph = sw.phase_timers(c)
+    print(f"chain {c}: resamples {st[c,1]} ids/step {st[c,0]/(ns*w['K']):.1f} total {ph[14]/1e6:.1f} Mcycles = {ph[14]/sw.clock_hz*1e3:.1f} ms (wall {ph[15]/1e5:.1f} ms)")
+    for i in range(14):
+        if ph[i]:
+            print(f"   {names[i]:22s} {ph[i]/1e6:9.2f} Mcyc  {100.0*ph[i]/ph[14]:5.1f} %   {ph[i]/ns:9.0f} cyc/obs")

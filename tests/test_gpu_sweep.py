@@ -96,6 +96,32 @@ def test_q2_mode_history_permuted_like___pmdi(pkg, O, P, n, N):
     assert (a["s"] != b["s"]).any()
 
 
+def test_both_forms_of_the_sweep_for_K_gt_1(pkg, O, monkeypatch):
+    """K > 1 runs either as one workgroup per chain or as K cooperating workgroups (one per dataset, hand-off per swept
+    observation); small batches default to the split form, so the single-workgroup form is forced here -- and the split
+    form with more chains than fit at once (workgroups of a chain queue behind each other's chains)."""
+    rng = np.random.default_rng(21)
+    data, kinds = make_mixed(rng, 240)
+    monkeypatch.setenv("PMDI_KSPLIT", "0")
+    g = _compare_run(pkg, O, data, kinds, 9, 256, 3, 33, 60)
+    assert not g.sw.split
+    monkeypatch.setenv("PMDI_KSPLIT", "1")
+    g = _compare_run(pkg, O, data, kinds, 9, 256, 3, 33, 60)
+    assert g.sw.split
+    # 700 chains x 3 datasets = 2 100 workgroups: several times the resident capacity
+    Cn, N, P, n = 700, 6, 64, 240
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=Cn, seed=1234)
+    assert sw.split
+    s = rng.integers(1, N + 1, size=(Cn, n, 3))
+    order = np.stack([rng.permutation(n) + 1 for _ in range(Cn)])
+    hyp = [random_hypers(rng, N, 3) for _ in range(Cn)]
+    r = sw.sweep(1, s, order, 60, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]))
+    for c in (0, 1, 7, 8, 349, 698, 699):
+        o = O.Oracle(data, kinds, N, P, seed=1234 + c).sweep(1, s[c], order[c], 60, hyp[c][0], hyp[c][1])
+        assert (r["s"][c] == o["s"]).all() and int(r["p_star"][c]) == o["p_star"]
+        assert r["stats"][c]["n_operations"] == o["stats"]["n_operations"] and r["stats"][c]["n_clones"] == o["stats"]["n_clones"]
+
+
 def test_feature_flags(pkg, O):
     rng = np.random.default_rng(2)
     data, kinds = make_mixed(rng, 200)
