@@ -107,6 +107,25 @@ def oracle_chain(w, state, n_iter, seed, progress=False):
     return out
 
 
+def host_core_share():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each
+    tenant a share of a large host: 256 hardware threads visible, 16 cores' worth of quota)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                cores = min(cores, max(1, q // pr))
+        except Exception:
+            pass
+    return cores
+
+
 def _cpu_worker(args):
     name, scale, path, chain, n_iter, seed = args
     sys.path.insert(0, ROOT)
@@ -123,7 +142,7 @@ def cpu_baseline(w, scale, states, budget_s):
     `julia -p`), each continuing a different settled chain of the GPU run; the iteration count is sized from one
     probe iteration so that the leg stays near `budget_s` seconds."""
     import multiprocessing as mp
-    host_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    host_cores = host_core_share()
     t0 = time.perf_counter()
     probe = oracle_chain(w, states[0], 1, 5, progress=True)[0]          # also: the 1-core figure with the box otherwise idle
     n_iter = int(max(1, min(8, (budget_s - probe[0]) // max(probe[0] * 1.3, 1e-3))))

@@ -915,12 +915,16 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
                 const gcint src = s.part[cur];
                 const gint dst = s.part[cur ^ 1];
-                // live marks, then old id -> new id, in LDS (the term buffer is idle) when the ids fit;
-                // otherwise the per-id scratch tables in global memory
-                const bool lm = oldmax + 1 <= 2 * a.terms_cap;
+                // Occupancy of every old id after the gather, then old id -> new id, in LDS (the term buffer and the hash / list
+                // tables are idle here) when the ids fit; otherwise the per-id scratch tables in global memory.  The new counts
+                // (:338) are the old ids' occupancies carried over to their new numbers: the histogram is taken while the gathered
+                // entries are in registers, so the second pass over the N x P table only exists to rewrite ids that moved, and is
+                // skipped when the live ids are exactly 1..U' already.
+                lint hist = sh.h1.key;                            // 9 * PMDI_HT_SIZE contiguous ints
+                const bool lm = oldmax + 1 <= 2 * a.terms_cap && oldmax + 1 <= 9 * PMDI_HT_SIZE;
                 lint lmap = (lint)sh.term;
                 PHR(3);   // (dataset loop top)
-                if (lm) for (int e = tid; e <= oldmax; e += T) lmap[e] = 0;
+                if (lm) for (int e = tid; e <= oldmax; e += T) { lmap[e] = 0; hist[e] = 0; }
                 for (int id = 1 + tid; id <= oldmax; id += T) s.counts[id] = 0;   // (:326)
                 __syncthreads();
                 for (int pb = 0; pb < P; pb += T) {               // particle[:, partstar, k] (:322)
@@ -928,61 +932,68 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                     if (p < P) {
                         const int an = ancp[p];
                         sidp[p] = (int)pidk[an];                  // (:323)
-                        int nn = 0;
-                        for (; nn + 4 <= N; nn += 4) {            // four independent gathers in flight
-                            const int v0 = src[nn * P + an], v1 = src[(nn + 1) * P + an], v2 = src[(nn + 2) * P + an], v3 = src[(nn + 3) * P + an];
-                            dst[nn * P + p] = v0; dst[(nn + 1) * P + p] = v1; dst[(nn + 2) * P + p] = v2; dst[(nn + 3) * P + p] = v3;
-                            if (lm) { lmap[v0] = 1; lmap[v1] = 1; lmap[v2] = 1; lmap[v3] = 1; }
-                            else { s.ncop[v0] = 1; s.ncop[v1] = 1; s.ncop[v2] = 1; s.ncop[v3] = 1; }
-                        }
-                        for (; nn < N; ++nn) {
-                            const int v = src[nn * P + an];
-                            dst[nn * P + p] = v;
-                            if (lm) lmap[v] = 1; else s.ncop[v] = 1;
+                        for (int nn = 0; nn < N; nn += 4) {       // four independent gathers in flight
+                            int v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = (nn + u < N) ? src[(nn + u) * P + an] : 0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (nn + u < N) dst[(nn + u) * P + p] = v[u];
+                            if (lm) {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    int cnt;
+                                    if (wave_group(v[u], nn + u < N, cnt)) atomicAdd(gen(&hist[v[u]]), cnt);
+                                }
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) if (nn + u < N) s.ncop[v[u]] = 1;
+                            }
                         }
                     }
                 }
                 __syncthreads();
                 PHR(4);   // gather
                 for (int p = tid; p < P; p += T) pidk[p] = (int)sidp[p];
-                // sort(unique(particle)) ascending -> 1..U' (:329): scan of live marks
+                // sort(unique(particle)) ascending -> 1..U' (:329): scan of the live ids
                 unsigned long long carry = 0;
                 for (int b = 0; b < oldmax; b += T) {
                     const int id = 1 + b + tid;
-                    const bool live = (id <= oldmax) && (lm ? lmap[id] != 0 : s.ncop[id] != 0);
+                    const int occ = (lm && id <= oldmax) ? hist[id] : 0;
+                    const bool live = (id <= oldmax) && (lm ? occ != 0 : s.ncop[id] != 0);
                     unsigned long long tot;
                     const unsigned long long ex = block_flag_scan<T>(live, false, false, tot, gen(sh.scan)) + carry;
-                    if (live) { if (lm) lmap[id] = (int)ex + 1; else s.firstc[id] = (int)ex + 1; }
+                    if (live) {
+                        if (lm) { lmap[id] = (int)ex + 1; s.counts[(int)ex + 1] = occ; }     // (:338)
+                        else s.firstc[id] = (int)ex + 1;
+                    }
                     carry += tot;
                 }
                 const int newmax = (int)carry;
                 PHR(5);   // id scan
-                // relabel + recount (:331-338); the histogram lives in LDS (the hash/list tables are
-                // idle here) when the renumbered ids fit, with wave-aggregated adds either way
-                lint hist = sh.h1.key;                            // 9 * PMDI_HT_SIZE contiguous ints
-                const bool lhist = newmax < 9 * PMDI_HT_SIZE;
-                if (lhist) for (int e = tid; e <= newmax; e += T) hist[e] = 0;
                 __syncthreads();
 #define PMDI_NEWID(id_) (lm ? lmap[(id_)] : (s.ncop[(id_)] ? s.firstc[(id_)] : 0))
                 const bool moves = newmax > 0 && PMDI_NEWID(newmax) != newmax;   // else ids 1..newmax stay put
-                for (int pb = 0; pb < P; pb += T) {
-                    const int p = pb + tid;
-                    const bool valid = p < P;
-                    for (int nn0 = 0; nn0 < N; nn0 += 4) {            // four labels per round: their reads overlap
-                        int v[4];
+                // relabel (:331-337) -- and, on the global-table path, recount (:338)
+                if (moves || !lm) {
+                    for (int pb = 0; pb < P; pb += T) {
+                        const int p = pb + tid;
+                        const bool valid = p < P;
+                        for (int nn0 = 0; nn0 < N; nn0 += 4) {            // four labels per round: their reads overlap
+                            int v[4];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = (valid && nn0 + u < N) ? dst[(nn0 + u) * P + p] : 0;
-                        if (moves) {                                   // else every live id keeps its number
+                            for (int u = 0; u < 4; ++u) v[u] = (valid && nn0 + u < N) ? dst[(nn0 + u) * P + p] : 0;
+                            if (moves) {                                   // else every live id keeps its number
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (valid && nn0 + u < N) { v[u] = PMDI_NEWID(v[u]); dst[(nn0 + u) * P + p] = v[u]; }
-                        }
+                                for (int u = 0; u < 4; ++u)
+                                    if (valid && nn0 + u < N) { v[u] = PMDI_NEWID(v[u]); dst[(nn0 + u) * P + p] = v[u]; }
+                            }
+                            if (!lm) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            if (nn0 + u < N) {
-                                int cnt;
-                                if (wave_group(v[u], valid, cnt)) {
-                                    if (lhist) atomicAdd(gen(&hist[v[u]]), cnt); else atomicAdd(gen(&s.counts[v[u]]), cnt);
+                                for (int u = 0; u < 4; ++u) {
+                                    if (nn0 + u < N) {
+                                        int cnt;
+                                        if (wave_group(v[u], valid, cnt)) atomicAdd(gen(&s.counts[v[u]]), cnt);
+                                    }
                                 }
                             }
                         }
@@ -990,13 +1001,11 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 }
                 __syncthreads();
                 PHR(6);   // relabel + recount
-                if (lhist) {
-                    for (int e = 1 + tid; e <= newmax; e += T) s.counts[e] = hist[e];
-                    __syncthreads();
-                    for (int e = tid; e < 9 * PMDI_HT_SIZE; e += T)       // tables back to empty (h2.b = INF)
+                if (lm) {
+                    for (int e = tid; e <= oldmax && e < 9 * PMDI_HT_SIZE; e += T)       // tables back to empty (h2.b = INF)
                         hist[e] = (e >= 4 * PMDI_HT_SIZE && e < 5 * PMDI_HT_SIZE) ? PMDI_INF_I : 0;
                 }
-                PHR(7);   // counts copy + table reset
+                PHR(7);   // table reset
                 if (moves) {
                     // clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending (:336):
                     // batches in ascending order, load -> barrier -> store
