@@ -927,26 +927,38 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 if (lm) for (int e = tid; e <= oldmax; e += T) { lmap[e] = 0; hist[e] = 0; }
                 for (int id = 1 + tid; id <= oldmax; id += T) s.counts[id] = 0;   // (:326)
                 __syncthreads();
-                for (int pb = 0; pb < P; pb += T) {               // particle[:, partstar, k] (:322)
-                    const int p = pb + tid;
-                    if (p < P) {
-                        const int an = ancp[p];
-                        sidp[p] = (int)pidk[an];                  // (:323)
-                        for (int nn = 0; nn < N; nn += 4) {       // four independent gathers in flight
-                            int v[4];
+                {
+                    // the pass is a chain of L2 round trips (the ancestors' columns, then this slot's column): RB gathers of a
+                    // particle are in flight together and the next particle's ancestor is fetched a round ahead
+                    constexpr int RB = 10;
+                    int an_next = tid < P ? (int)ancp[tid] : 0;
+                    for (int pb = 0; pb < P; pb += T) {           // particle[:, partstar, k] (:322)
+                        const int p = pb + tid;
+                        const int an = an_next;
+                        if (p + T < P) an_next = ancp[p + T];
+                        if (p < P) {
+                            sidp[p] = (int)pidk[an];              // (:323)
+                            for (int nn = 0; nn < N; nn += RB) {
+                                int v[RB];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) v[u] = (nn + u < N) ? src[(nn + u) * P + an] : 0;
+                                for (int u = 0; u < RB; ++u) v[u] = (nn + u < N) ? src[(nn + u) * P + an] : 0;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) if (nn + u < N) dst[(nn + u) * P + p] = v[u];
-                            if (lm) {
+                                for (int u = 0; u < RB; ++u) if (nn + u < N) dst[(nn + u) * P + p] = v[u];
+                                if (lm) {
+#ifndef PMDI_RS_PLAIN_ATOMICS      // (A/B: one LDS add per entry instead -- measured 19 % slower per event at full load)
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    int cnt;
-                                    if (wave_group(v[u], nn + u < N, cnt)) atomicAdd(gen(&hist[v[u]]), cnt);
+                                    for (int u = 0; u < RB; ++u) {
+                                        int cnt;
+                                        if (wave_group(v[u], nn + u < N, cnt)) atomicAdd(gen(&hist[v[u]]), cnt);
+                                    }
+#else
+#pragma unroll
+                                    for (int u = 0; u < RB; ++u) if (nn + u < N) __hip_atomic_fetch_add(gen(&hist[v[u]]), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                                } else {
+#pragma unroll
+                                    for (int u = 0; u < RB; ++u) if (nn + u < N) s.ncop[v[u]] = 1;
                                 }
-                            } else {
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) if (nn + u < N) s.ncop[v[u]] = 1;
                             }
                         }
                     }
@@ -978,18 +990,23 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                     for (int pb = 0; pb < P; pb += T) {
                         const int p = pb + tid;
                         const bool valid = p < P;
-                        for (int nn0 = 0; nn0 < N; nn0 += 4) {            // four labels per round: their reads overlap
-                            int v[4];
+                        constexpr int RB = 10;
+                        for (int nn0 = 0; nn0 < N; nn0 += RB) {           // RB labels per round: their reads overlap
+                            int v[RB];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) v[u] = (valid && nn0 + u < N) ? dst[(nn0 + u) * P + p] : 0;
+                            for (int u = 0; u < RB; ++u) v[u] = (valid && nn0 + u < N) ? dst[(nn0 + u) * P + p] : 0;
                             if (moves) {                                   // else every live id keeps its number
 #pragma unroll
-                                for (int u = 0; u < 4; ++u)
-                                    if (valid && nn0 + u < N) { v[u] = PMDI_NEWID(v[u]); dst[(nn0 + u) * P + p] = v[u]; }
+                                for (int u = 0; u < RB; ++u)
+                                    if (valid && nn0 + u < N) {
+                                        const int nv = PMDI_NEWID(v[u]);
+                                        if (nv != v[u]) dst[(nn0 + u) * P + p] = nv;
+                                        v[u] = nv;
+                                    }
                             }
                             if (!lm) {
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
+                                for (int u = 0; u < RB; ++u) {
                                     if (nn0 + u < N) {
                                         int cnt;
                                         if (wave_group(v[u], valid, cnt)) atomicAdd(gen(&s.counts[v[u]]), cnt);
