@@ -308,7 +308,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if (K < 1 || K > PMDI_KMAX_I) return fail(PMDI_E_ARG, "K=%d outside 1..%d", K, PMDI_KMAX_I);
     if (n < 2 || n > 0x7fffffffLL / 4) return fail(PMDI_E_ARG, "n=%lld out of range", n);
     if (!(N <= n && N > 1)) return fail(PMDI_E_ARG, "Number of clusters must be greater than 1 and not greater than the number of observations");
-    if (N > 64) return fail(PMDI_E_ARG, "N=%d: this build supports N <= 64", N);
+    if (N > 128) return fail(PMDI_E_ARG, "N=%d: this build supports N <= 128 (the mutation CDF of a particle class is formed by one wave, two labels per lane)", N);
     if (P < 2) return fail(PMDI_E_ARG, "Conditional particle filter requires 2 or more particles");
     if (P > 1048575) return fail(PMDI_E_ARG, "P=%d too large", P);
     if (cfg->n_chains < 1) return fail(PMDI_E_ARG, "n_chains must be >= 1");
@@ -434,7 +434,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         auto configure = [&](int T, int &terms_cap, int &pid_lds, int &pp_lds) -> int {
             int tc = env_int("PMDI_TERMS_CAP", 1024);
             if (tc < P) tc = P;
-            if (tc < (T / 64) * 128) tc = (T / 64) * 128;
+            if (tc < (T / 64) * (N > 64 ? 256 : 128)) tc = (T / 64) * (N > 64 ? 256 : 128);   // per-wave exchange areas of the CDF stage
             if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
             if (tc < 384) tc = 384;                                   // the known-prefix label table (3 x 256 ints) lives there
             terms_cap = tc;

@@ -1380,7 +1380,83 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
             PH(4); FRESH_LANE_IDS();
             const Dual<double> cdfp = dual(small, sh.cdf, s.cdf);
-            {
+            if (N > 64) {
+                // 64 < N <= 128: one class per wave, the labels in two chunks of 64 lanes (same arithmetic, same order:
+                // c[n] = e[0] + (e[1] + ... + e[n]) is Julia's accumulate_pairwise! for fewer than 129 elements)
+                double *wv = gen(sh.term + wave * 256);      // v[0..127], e[0..127]
+                for (int r = wave; r < ncls; r += T / 64) {
+                    double v2[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int nn = lane + 64 * c;
+                        if (nn < N) {
+                            if (small) v2[c] = sh.lpl[sh.h1.a[ht_find(sh.h1, sh.item_id[r * N + nn])]];
+                            else v2[c] = s.lp[part[nn * P + cl.lead(r)]];
+                            wv[nn] = v2[c];
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    double m = wv[0];
+                    for (int j = 1; j < N; ++j) { const double t = wv[j]; m = (t > m) ? t : m; }
+                    double e2[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int nn = lane + 64 * c;
+                        if (nn < N) {
+                            double e = v2[c] - m;
+                            e = exp(e);
+                            e = e * pik[nn];
+                            e2[c] = e;
+                            wv[128 + nn] = e;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const double e0 = wv[128];
+                    double c2[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int nn = lane + 64 * c;
+                        if (nn < N) {
+                            double s_ = 0.0;
+                            for (int j = 1; j <= nn; ++j) { const double t = wv[128 + j]; s_ = (j == 1) ? t : s_ + t; }
+                            c2[c] = (nn == 0) ? e2[c] : e0 + s_;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) { const int nn = lane + 64 * c; if (nn < N) wv[nn] = c2[c]; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const double fN = wv[N - 1];
+                    unsigned long long mo[2], mt[2];
+                    double cd2[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const int nn = lane + 64 * c;
+                        cd2[c] = c2[c] / fN;
+                        mo[c] = __ballot(nn < N && (cd2[c] == 1.0 || nn == N - 1));
+                        mt[c] = __ballot(nn < N && cd2[c] < 0x1p-53);
+                        if (nn < N) cdfp[(size_t)r * (N + 2) + nn] = cd2[c];
+                    }
+                    if (lane == 0) {
+                        cdfp[(size_t)r * (N + 2) + N] = log(fN) + m;
+                        const int nstar = mo[0] ? __ffsll((long long)mo[0]) - 1 : 64 + __ffsll((long long)mo[1]) - 1;
+                        bool onehot;
+                        if (nstar < 64) {
+                            const unsigned long long below = (nstar == 0) ? 0ull : ((1ull << nstar) - 1ull);
+                            onehot = (mt[0] & below) == below;
+                        } else {
+                            const int ns1 = nstar - 64;
+                            const unsigned long long below = (ns1 == 0) ? 0ull : ((1ull << ns1) - 1ull);
+                            onehot = mt[0] == ~0ull && (mt[1] & below) == below;
+                        }
+                        cdfp[(size_t)r * (N + 2) + N + 1] = onehot ? (double)nstar : -1.0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
                 const int G = 64 / N;
                 const int g = lane / N, nn = lane - g * N;
                 const int gbase = (g < G) ? g * N : 0;

@@ -131,9 +131,11 @@ def test_feature_flags(pkg, O):
     _compare_run(pkg, O, data, kinds, 6, 64, 1, 61, 50, flags=fl0)
 
 
-@pytest.mark.parametrize("N,P,n1,n", [(2, 2, 1, 40), (2, 33, 40, 40), (10, 17, 2, 60), (64, 128, 16, 130), (5, 4096, 10, 50)])
+@pytest.mark.parametrize("N,P,n1,n", [(2, 2, 1, 40), (2, 33, 40, 40), (10, 17, 2, 60), (64, 128, 16, 130), (5, 4096, 10, 50),
+                                      (65, 64, 20, 200), (100, 96, 30, 260), (128, 256, 10, 300)])
 def test_edges(pkg, O, N, P, n1, n):
-    # n1 = 1: no known prefix; n1 = n: a single swept observation; N = 2 / N = 64: label-count limits;
+    # n1 = 1: no known prefix; n1 = n: a single swept observation; N = 2 / N = 64: one class per <= 64-lane group;
+    # N = 65 / 100 / 128: a class's CDF spans two 64-lane chunks of a wave (the reference allows any N <= n, src/pmdi.jl:54);
     # P not a multiple of the wave size; P = 4096: four particles per lane
     rng = np.random.default_rng(N * 1000 + P)
     z = rng.integers(0, 2, n)
