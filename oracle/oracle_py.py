@@ -57,6 +57,8 @@ def lib():
     L.pmdi_oracle_sweep.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, dbl, vp, vp, vp, vp, vp]
     L.pmdi_oracle_feature_select.restype = C.c_int
     L.pmdi_oracle_feature_select.argtypes = [vp, i64, vp, vp, vp]
+    L.pmdi_oracle_work.restype = None
+    L.pmdi_oracle_work.argtypes = [vp, vp, vp]
     L.pmdi_oracle_export.restype = C.c_int
     L.pmdi_oracle_export.argtypes = [vp, vp, vp, vp, vp]
     L.pmdi_oracle_cluster_new.restype = vp
@@ -198,6 +200,12 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"pmdi_oracle_feature_select failed rc={rc}")
         return flags, probs
+
+    def work(self):
+        """(updates[K], moved[K]) of the last sweep: cluster_add! calls (:300), renumbering deepcopies (:336)."""
+        up = np.zeros(self.K, dtype=np.int64); mv = np.zeros(self.K, dtype=np.int64)
+        self.L.pmdi_oracle_work(self.h, _ptr(up), _ptr(mv))
+        return up, mv
 
     def export(self):
         K, N, P = self.K, self.N, self.P

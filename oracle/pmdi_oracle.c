@@ -373,6 +373,7 @@ struct pmdi_oracle {
     int64_t *sstar_id;      /* [k][p]     src/pmdi.jl:145 */
     uint8_t *sstar;         /* [k][i][p]  = sstar[p,i,k], src/pmdi.jl:146 */
     int64_t *maxid;         /* [k] running maximum(particle_k) */
+    int64_t last_updates[8], last_moved[8];   /* per dataset, last sweep: cluster_add! calls at :300, deepcopies at :336 */
     /* scratch */
     int64_t *partstar, *tmp_i64, *idmap;
     double  *tmp_d;
@@ -546,6 +547,7 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
 
     double t0 = now_seconds();
     pmdi_oracle_stats st; memset(&st, 0, sizeof(st));
+    memset(h->last_updates, 0, sizeof(h->last_updates)); memset(h->last_moved, 0, sizeof(h->last_moved));
     double *logweight = h->logweight;
     for (int p = 0; p < P; ++p) logweight[p] = lw_init;
 
@@ -694,6 +696,7 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                     st.n_clones += 1;
                 }
                 cl_add(pl, id, i, flags[k]);          /* :300 */
+                h->last_updates[k] += 1;
                 if (id != c) {                        /* :301-308 */
                     for (int part = 0; part < P; ++part) {
                         int64_t s_id = ss[part];
@@ -766,7 +769,7 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                     if (!idmap[id]) continue;
                     next += 1;
                     idmap[id] = next;
-                    if (id != next) cl_copy(pl, next, id);   /* :336 */
+                    if (id != next) { cl_copy(pl, next, id); h->last_moved[k] += 1; }   /* :336 */
                 }
                 for (int64_t e = 0; e < (int64_t)P * N; ++e) {
                     particle[e] = idmap[particle[e]];
@@ -910,4 +913,11 @@ void pmdi_oracle_psm_counts(const uint8_t *samples, int64_t S, int32_t K, int64_
                 }
                 counts[((size_t)k * (row_hi - row_lo) + (i - row_lo)) * n + j] = c;
             }
+}
+
+/* per dataset, last sweep: distinct clusters updated (cluster_add! at src/pmdi.jl:300) and clusters moved down by the
+ * renumbering of the resampling events (deepcopy at :336) -- what the device's work counters are checked against */
+void pmdi_oracle_work(const pmdi_oracle *h, int64_t *updates, int64_t *moved)
+{
+    for (int k = 0; k < h->K; ++k) { updates[k] = h->last_updates[k]; moved[k] = h->last_moved[k]; }
 }

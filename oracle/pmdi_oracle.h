@@ -93,6 +93,10 @@ int pmdi_oracle_feature_select(pmdi_oracle *h, int64_t iter,
 int pmdi_oracle_export(const pmdi_oracle *h, int64_t *particle, int64_t *counts,
                        int64_t *cluster_n, int64_t *max_id);
 
+/* Per dataset, last sweep: distinct clusters updated (cluster_add! at src/pmdi.jl:300) and clusters moved down by the
+ * renumbering of resampling events (deepcopy at :336). */
+void pmdi_oracle_work(const pmdi_oracle *h, int64_t *updates, int64_t *moved);
+
 /* --- cluster plugin protocol on stand-alone clusters (unit tests) -------- */
 typedef struct pmdi_oracle_cluster pmdi_oracle_cluster;
 pmdi_oracle_cluster *pmdi_oracle_cluster_new(const pmdi_oracle_dataset *ds, int64_t n);

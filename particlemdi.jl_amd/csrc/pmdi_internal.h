@@ -122,6 +122,7 @@ struct ClusterBatchArgs {
 
 struct FeatSelArgs {
     int K, N, sumD;
+    int ltile;              // categorical levels counted per pass of the per-lane LDS histogram (set by the launcher)
     long long n;
     unsigned iter;
     unsigned long long seed;

@@ -127,7 +127,7 @@ __global__ void cluster_logmarginal_kernel(const ClusterBatchArgs a)
 __global__ void __launch_bounds__(256) featsel_label_kernel(const FeatSelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *lcnt = (int *)smem;                  // [256][L] categorical level counts
+    int *lcnt = (int *)smem;                  // [lanes][ltile] categorical level counts
     __shared__ int s_first, s_count;
     const int N = a.N, K = a.K;
     const long long n = a.n;
@@ -159,13 +159,23 @@ __global__ void __launch_bounds__(256) featsel_label_kernel(const FeatSelArgs a)
             }
             val = logmarginal_one(d, cn, sb.y, nullptr, 0, q);
         } else if (d.kind == K_CATEGORICAL) {
-            int *mine = lcnt + (size_t)tid * d.L;
-            for (int l = 0; l < d.L; ++l) mine[l] = 0;
-            for (long long i = first; i < n; ++i) {
-                if (traj[i] != u) continue;
-                mine[glob(d.xi)[(size_t)i * D + q] - 1] += 1;
+            // calc_logmarginal(::CategoricalCluster) (categorical_cluster.jl:53-66) with the level counts held in LDS a tile of
+            // levels at a time (any number of levels fits; the members are re-read once per tile), terms added in level order
+            const int Lt = a.ltile;
+            int *mine = lcnt + (size_t)tid * Lt;
+            const int mc = glob(d.maxcol)[q];                       // 2 * nlevels_q
+            val = 0.0;
+            val += glob(d.lghtab)[2 * mc] - glob(d.lghtab)[2 * (mc + cn)];
+            for (int l0 = 0; l0 < mc; l0 += Lt) {
+                for (int l = 0; l < Lt; ++l) mine[l] = 0;
+                for (long long i = first; i < n; ++i) {
+                    if (traj[i] != u) continue;
+                    const int x = glob(d.xi)[(size_t)i * D + q] - 1 - l0;
+                    if (x >= 0 && x < Lt) mine[x] += 1;
+                }
+                const int hi = min(Lt, mc - l0);
+                for (int r = 0; r < hi; ++r) val += glob(d.lghtab)[2 * mine[r] + 1];
             }
-            val = logmarginal_one(d, cn, 0.0, mine, 0, q);
         } else {
             long long S = 0;
             for (long long i = first; i < n; ++i) {
@@ -422,11 +432,17 @@ hipError_t pmdi_launch_label_counts(const int *s, int *counts, int n_rows, long 
 
 hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream)
 {
-    int Lmax = 1;
-    for (int k = 0; k < a.K; ++k) if (a.ds[k].kind == K_CATEGORICAL && a.ds[k].L > Lmax) Lmax = a.ds[k].L;
-    const size_t lds = (size_t)256 * Lmax * 4;
-    if (lds > 60 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(featsel_label_kernel, dim3(n_chains * a.K * a.N), dim3(256), lds, stream, a);
+    int Lmax = 1, lanes = 1;
+    for (int k = 0; k < a.K; ++k)
+        if (a.ds[k].kind == K_CATEGORICAL) {
+            if (a.ds[k].L > Lmax) Lmax = a.ds[k].L;
+            if (a.ds[k].D > lanes) lanes = a.ds[k].D;
+        }
+    if (lanes > 256) lanes = 256;
+    FeatSelArgs b = a;
+    b.ltile = Lmax < 12288 / lanes ? Lmax : 12288 / lanes;       // <= 48 KiB of level counts per workgroup
+    const size_t lds = (size_t)lanes * b.ltile * 4;              // lanes beyond min(D, 256) never touch their slice
+    hipLaunchKernelGGL(featsel_label_kernel, dim3(n_chains * a.K * a.N), dim3(256), lds, stream, b);
     hipLaunchKernelGGL(featsel_combine_kernel, dim3((a.sumD + 255) / 256, n_chains), dim3(256), 0, stream, a);
     return hipGetLastError();
 }

@@ -72,6 +72,32 @@ def test_feature_selection_matches_oracle(pkg, O):
             off += D
 
 
+def test_feature_selection_with_many_categorical_levels(pkg, O):
+    """A categorical dataset with 150 levels (the per-lane level histogram of the feature-selection kernel is tiled over
+    levels; the null marginal of src/pmdi.jl:120-128 runs the same kernel inside pmdi_create): flags and scores == oracle,
+    integer statistics bit-exact; a sweep on the same data for good measure."""
+    rng = np.random.default_rng(8)
+    n, N, P = 400, 6, 64
+    z = rng.integers(0, 3, n)
+    cat = 1 + ((rng.integers(0, 50, (n, 7)) + 50 * z[:, None]) % 150)
+    cat[0, :] = 150
+    gau = rng.normal(size=(n, 4)) + 2.0 * (z[:, None] - 1)
+    data, kinds = [cat.astype(np.int64), gau], ["categorical", "gaussian"]
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=2, seed=3)
+    o = O.Oracle(data, kinds, N, P, seed=3)
+    traj = np.stack([z + 1, (z + 1) % 3 + 1], axis=1)
+    fl, pr = sw.feature_select(2, np.repeat(traj[None], 2, 0))
+    of, op = o.feature_select(2, traj)
+    assert (fl[0] == np.concatenate(of)).all()
+    assert (pr[0][:7] == op[0]).all() and np.allclose(pr[0][7:], op[1], rtol=1e-9)
+    Pi, Phi = random_hypers(rng, N, 2)
+    order = rng.permutation(n) + 1
+    s = rng.integers(1, N + 1, size=(n, 2))
+    rg = sw.sweep(1, np.repeat(s[None], 2, 0), np.repeat(order[None], 2, 0), 100, np.repeat(Pi[None], 2, 0), np.repeat(Phi[None], 2, 0))
+    ro = o.sweep(1, s, order, 100, Pi, Phi)
+    assert (rg["s"][0] == ro["s"]).all()
+
+
 def test_pmdi_driver_csv(pkg, tmp_path):
     from particlemdi_jl_amd import workloads
     from particlemdi_jl_amd.pmdi import pmdi

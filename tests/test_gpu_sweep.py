@@ -54,6 +54,10 @@ def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, b
         assert np.allclose(rg["logweight"], ro["logweight"], rtol=1e-9, atol=1e-8)
         for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
             assert rg["stats"][key] == ro["stats"][key], key
+        # the work counters behind bench.py's algorithmic byte count: clusters updated / cloned / moved per dataset
+        wk, (up, mv) = g.sw.work_counters()[0], o.work()
+        assert (wk[:, 1] == up).all() and (wk[:, 3] == mv).all() and wk[:, 2].sum() == ro["stats"]["n_clones"]
+        assert (wk[:, 0] >= 1).all() and wk[:, 0].sum() <= ro["stats"]["n_operations"]      # evaluated <= the reference's count
         s = ro["s"]
     if check_state:
         eg, eo = g.sw.export_state(0), o.export()
