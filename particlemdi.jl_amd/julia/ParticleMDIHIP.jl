@@ -4,6 +4,9 @@
 # the build container nor the GPU box has a julia binary (DESIGN.md).  The Python twin of this
 # file (particlemdi.jl_amd/pmdi.py) drives the same ABI and is what the GPU tests exercise.
 #
+# Two drivers: `pmdi` replaces only the sweep (the reference's own Julia hyper-parameter functions stay, as the
+# north star describes); `pmdi_device` runs the whole iteration on the device (pmdi_gibbs_*, pmdi_csv_*).
+#
 # What it does: `ParticleMDIHIP.pmdi(...)` has the signature, the asserts and the CSV output of
 # `ParticleMDI.pmdi` (src/pmdi.jl:36-40, 50-55, 147-158, 377-383).  The hyper-parameter
 # updates and label alignment are the reference's own functions, called from the installed
@@ -198,6 +201,87 @@ function pmdi(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float64, ite
         close(fileid)
         featureFile !== nothing && close(featureFile)
     finally
+        ccall((:pmdi_destroy, LIB), Cint, (Ptr{Cvoid},), h)
+    end
+    return
+end
+
+"""
+    pmdi_device(dataFiles, dataTypes, N, particles, ρ, iter, outputFile; thin, featureSelect, dataNames,
+                seed = rand(UInt64), device = 0, q2_mode = 0)
+
+The same run with EVERYTHING of an iteration on the MI355X (include/pmdi_hip.h, pmdi_gibbs_*): shuffle!(order_obs),
+update_M!, update_γ!, update_Φ!, update_Z, update_v (evaluated without the N^K tables of src/pmdi.jl:69-92), the sweep,
+feature selection and align_labels! (contingency tables) are device kernels; the CSV rows are written by the library's
+byte-compatible writer (pmdi_csv_*).  Host-side draws become counter-based Philox variates keyed on `seed`
+(SURVEY 8 rows f1, f2, f4).  `pmdi` above keeps the reference's own Julia functions for those parts.
+"""
+function pmdi_device(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float64, iter::Int64,
+                     outputFile::String; thin::Int64 = 1, featureSelect::Union{String, Nothing} = nothing,
+                     dataNames = nothing, seed::UInt64 = rand(UInt64), device::Integer = 0, q2_mode::Integer = 0)
+    kinds = [device_kind(t) for t in dataTypes]
+    any(k -> k < 0, kinds) && return ParticleMDI.pmdi(dataFiles, dataTypes, N, particles, ρ, iter, outputFile;
+                                                      thin = thin, featureSelect = featureSelect, dataNames = dataNames)
+    K = length(dataFiles)
+    n_obs = size(dataFiles[1], 1)
+    dataNames === nothing && (dataNames = ["K$i" for i in 1:K])
+    @assert length(dataTypes) == K "Number of datatypes not equal to number of datasets"
+    @assert all(size(d, 1) == n_obs for d in dataFiles) "Datasets don't have same number of observations. Each row must correspond to the same underlying observational unit across datasets."
+    @assert 0 < ρ < 1 "ρ must be between 0 and 1"
+    @assert 1 < N <= n_obs "Number of clusters must be greater than 1 and not greater than the number of observations"
+    @assert particles > 1 "Conditional particle filter requires 2 or more particles"
+    mats = [kinds[k] == 0 ? convert(Matrix{Float64}, dataFiles[k]) : convert(Matrix{Int64}, dataFiles[k]) for k in 1:K]
+    handle = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve mats begin
+        ds = [CDataset(kinds[k], Int32(size(mats[k], 2)), Int64(n_obs),
+                       kinds[k] == 0 ? pointer(mats[k]) : Ptr{Float64}(C_NULL),
+                       kinds[k] == 0 ? Ptr{Int64}(C_NULL) : pointer(mats[k])) for k in 1:K]
+        cfg = Ref(CConfig(PMDI_ABI_VERSION, Int32(device), Int32(K), Int32(N), Int32(particles), Int32(1),
+                          Int64(n_obs), seed, Int32(0), Int32(q2_mode), Int64(0), Int32(0), Int32(0)))
+        check(ccall((:pmdi_create, LIB), Cint, (Ref{CConfig}, Ptr{CDataset}, Ref{Ptr{Cvoid}}), cfg, ds, handle))
+    end
+    h = handle[]
+    g = Ref{Ptr{Cvoid}}(C_NULL)
+    csv = Ref{Ptr{Cvoid}}(C_NULL)
+    fcsv = Ref{Ptr{Cvoid}}(C_NULL)
+    try
+        check(ccall((:pmdi_gibbs_create, LIB), Cint, (Ptr{Cvoid}, Float64, Int32, Ref{Ptr{Cvoid}}),
+                    h, ρ, featureSelect === nothing ? 0 : 1, g))                 # src/pmdi.jl:59-66, 95-96, 106-110
+        names = [Base.unsafe_convert(Cstring, String(nm)) for nm in dataNames]
+        GC.@preserve dataNames begin
+            check(ccall((:pmdi_csv_open, LIB), Cint, (Cstring, Int32, Int64, Ptr{Cstring}, Ref{Ptr{Cvoid}}),
+                        outputFile, K, n_obs, names, csv))                       # :147-156
+            if featureSelect !== nothing
+                D = Int32[size(d, 2) for d in dataFiles]
+                check(ccall((:pmdi_csv_open_features, LIB), Cint, (Cstring, Int32, Ptr{Int32}, Ptr{Cstring}, Ref{Ptr{Cvoid}}),
+                            featureSelect, K, D, names, fcsv))                   # :111
+            end
+        end
+        flags = Vector{UInt8}(undef, sum(size(d, 2) for d in dataFiles))
+        write_flags() = begin
+            check(ccall((:pmdi_gibbs_get, LIB), Cint,
+                        (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}),
+                        g[], 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, flags))
+            check(ccall((:pmdi_csv_write_flags, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}), fcsv[], flags))
+        end
+        featureSelect === nothing || write_flags()                                # :116
+        t0 = time_ns()
+        check(ccall((:pmdi_csv_write_gibbs, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64), csv[], g[], 0, 0.0))   # :158
+        stats = Vector{Int64}(undef, 8)
+        for it in 1:iter
+            check(ccall((:pmdi_gibbs_iterate, LIB), Cint, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Ptr{Cvoid}), g[], 1, C_NULL, C_NULL))   # :165-375
+            check(ccall((:pmdi_gibbs_results, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Int64}, Ptr{Float64}),
+                        g[], stats, C_NULL, C_NULL, C_NULL))                     # synchronises; a kernel-side error surfaces here
+            ll = (time_ns() - t0) / 1.0e9                                        # :377
+            if it % thin == 0
+                check(ccall((:pmdi_csv_write_gibbs, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Float64), csv[], g[], 0, ll))   # :379
+                featureSelect === nothing || write_flags()                       # :381
+            end
+        end
+    finally
+        csv[] == C_NULL || ccall((:pmdi_csv_close, LIB), Cint, (Ptr{Cvoid},), csv[])
+        fcsv[] == C_NULL || ccall((:pmdi_csv_close, LIB), Cint, (Ptr{Cvoid},), fcsv[])
+        g[] == C_NULL || ccall((:pmdi_gibbs_destroy, LIB), Cint, (Ptr{Cvoid},), g[])
         ccall((:pmdi_destroy, LIB), Cint, (Ptr{Cvoid},), h)
     end
     return

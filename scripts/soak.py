@@ -1,5 +1,6 @@
 """Randomised parity soak: the HIP sweep (through the C ABI) against the oracle on many small random
-configurations -- data types, N, P, K, chains, quirk switch, flags, workgroup widths, launch-split thresholds.
+configurations -- data types, N (up to 128), P, K, chains, quirk switches (Q1, Q2), flags, workgroup widths, launch-split thresholds, both forms of
+the K > 1 sweep.
 Usage: python scripts/soak.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
@@ -12,7 +13,7 @@ def run(budget, seed, max_cases=10**9, verbose=True):
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     ncase = 0
-    saved = {k: os.environ.get(k) for k in ("PMDI_LIGHT_IDS", "PMDI_VERY_HEAVY")}
+    saved = {k: os.environ.get(k) for k in ("PMDI_LIGHT_IDS", "PMDI_VERY_HEAVY", "PMDI_KSPLIT")}
     try:
         while time.time() < t_end and ncase < max_cases:
             ncase += _one_case(rng)
@@ -29,7 +30,11 @@ def run(budget, seed, max_cases=10**9, verbose=True):
 
 def _one_case(rng):
     K = int(rng.integers(1, 4)); n = int(rng.integers(30, 220)); N = int(rng.integers(2, 21))
+    if rng.random() < 0.1:
+        N = int(rng.integers(65, min(n, 128) + 1)) if n > 65 else N      # two 64-lane chunks per class
     P = int(rng.choice([2, 8, 33, 64, 200, 256, 512, 1024])); Cn = int(rng.integers(1, 5)); q1 = int(rng.integers(0, 2))
+    q2 = int(rng.random() < 0.2)
+    os.environ["PMDI_KSPLIT"] = str(int(rng.integers(0, 2)))          # both forms of the K > 1 sweep
     if os.environ.get("PMDI_SOAK_BIG"):       # fewer, larger cases: more particles, labels, datasets, observations
         K = int(rng.integers(1, 5)); n = int(rng.integers(150, 500)); N = int(rng.integers(10, 51)); P = int(rng.choice([512, 1024, 2048, 4096]))
     block = int(rng.choice([0, 0, 0, 128, 256, 512, 1024])); n1 = int(rng.integers(1, n + 1)); iters = int(rng.integers(1, 5))
@@ -46,12 +51,12 @@ def _one_case(rng):
     sumD = sum(d.shape[1] for d in data)
     flags = (rng.random((Cn, sumD)) < 0.7).astype(np.uint8) if rng.random() < 0.3 else None
     seed = int(rng.integers(0, 2**31))
-    desc = f"K={K} n={n} N={N} P={P} C={Cn} q1={q1} T={block} n1={n1} it={iters} kinds={kinds} sep={sep} light={os.environ['PMDI_LIGHT_IDS']} vh={os.environ['PMDI_VERY_HEAVY']} flags={'y' if flags is not None else 'n'} seed={seed}"
+    desc = f"K={K} n={n} N={N} P={P} C={Cn} q1={q1} T={block} n1={n1} it={iters} kinds={kinds} sep={sep} light={os.environ['PMDI_LIGHT_IDS']} vh={os.environ['PMDI_VERY_HEAVY']} flags={'y' if flags is not None else 'n'} q2={q2} split={os.environ['PMDI_KSPLIT']} seed={seed}"
     try:
-        sw = pkg.Sweeper(data, kinds, N, P, n_chains=Cn, seed=seed, q1_mode=q1, block_threads=block)
+        sw = pkg.Sweeper(data, kinds, N, P, n_chains=Cn, seed=seed, q1_mode=q1, q2_mode=q2, block_threads=block)
     except Exception as e:
         return 0
-    orc = [O.Oracle(data, kinds, N, P, seed=seed + c, q1_mode=q1) for c in range(Cn)]
+    orc = [O.Oracle(data, kinds, N, P, seed=seed + c, q1_mode=q1, q2_mode=q2) for c in range(Cn)]
     s = rng.integers(1, N + 1, size=(Cn, n, K))
     Dcum = np.cumsum([d.shape[1] for d in data])[:-1]
     for it in range(1, iters + 1):
