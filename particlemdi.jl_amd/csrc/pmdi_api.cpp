@@ -135,6 +135,7 @@ struct pmdi_handle {
     long long light_ids = 0;
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    unsigned *start_sig = nullptr;   // signal memory: workgroups of the heaviest-chains launch that have started (hipStreamWaitValue32)
     int very_heavy = 0;          // the first `very_heavy` heavy chains of the launch order get a CU each (256-register build)
     bool phase_on = false;
     hipStream_t stream = nullptr;
@@ -243,14 +244,29 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
             SweepArgs av = a;
             av.two_per_cu = 0; av.rank_lo = 0; av.rank_hi = vh;
             HIP_TRY(hipStreamWaitEvent(h->stream3, h->ev_fork, 0));
+            // A workgroup of that build needs a CU to itself.  If the other two launches were released at the same moment their
+            // smaller workgroups would take a slot on every CU first and the heaviest chains -- the ones that bound the sweep --
+            // would start late, one by one, whenever a CU happens to drain (measured at cfg2: 1 020 ms for a launch whose chains
+            // take 550 ms).  So its workgroups count themselves in on entry and the other launches wait for that count.
+            const bool gate = h->start_sig != nullptr && !h->ksplit;
+            if (gate) av.start_sig = h->start_sig;      // (zero here: reset on `st` behind the previous sweep's join, below)
             e = pmdi_launch_sweep(av, (SweepArgs *)h->d_args3.p, vh, h->T, h->stream3);
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (heaviest chains): %s", hipGetErrorString(e));
             HIP_TRY(hipEventRecord(h->ev_join3, h->stream3));
+            if (gate) {
+                const unsigned n_wg = (unsigned)vh;
+                HIP_TRY(hipStreamWaitValue32(st, h->start_sig, n_wg, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+                HIP_TRY(hipStreamWaitValue32(h->stream2, h->start_sig, n_wg, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            }
         }
         a.rank_lo = vh; a.rank_hi = C;
         e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, st);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (heavy group): %s", hipGetErrorString(e));
-        if (vh > 0) HIP_TRY(hipStreamWaitEvent(st, h->ev_join3, 0));
+        if (vh > 0) {
+            HIP_TRY(hipStreamWaitEvent(st, h->ev_join3, 0));
+            if (h->start_sig && !h->ksplit) HIP_TRY(hipStreamWriteValue32(st, h->start_sig, 0, 0));   // re-arm the start gate
+        }
         SweepArgs al = a;
         al.group_sel = 0; al.rank_lo = 0; al.rank_hi = C;
         al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds;
@@ -488,6 +504,15 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess)
                 return bail(fail(PMDI_E_DEVICE, "stream/event creation failed"));
             h->very_heavy = (h->T == 512 && h->two_per_cu) ? env_int("PMDI_VERY_HEAVY", 128) : 0;
+            int can_wait = 0;
+            (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, cfg->device);
+            if (h->very_heavy > 0 && can_wait && env_int("PMDI_START_GATE", 1) != 0) {
+                void *sig = nullptr;
+                if (hipExtMallocWithFlags(&sig, 8, hipMallocSignalMemory) == hipSuccess) {
+                    h->start_sig = (unsigned *)sig; h->owned.push_back(sig);
+                    (void)hipMemset(sig, 0, 8);
+                }
+            }
         }
     }
     const int C = cfg->n_chains;

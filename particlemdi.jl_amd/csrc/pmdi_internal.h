@@ -13,7 +13,7 @@
 #define PMDI_ITEM_CAP 256   // (class, label) items of a fast-path step
 #define PMDI_ITEM_CAP_BIGN 384   // ... when N > 32 (N = 50: seven classes instead of five); must stay below PMDI_HT_SIZE
 #define PMDI_HT_SIZE 512    // entries per hash table (>= 2 * PMDI_ITEM_CAP, power of two)
-#define PMDI_CLS_LDS 128    // class-list slots per dataset kept in LDS
+#define PMDI_CLS_LDS 128    // class-list slots per dataset kept in LDS (64 measured 11 % slower at HL: chains with 64..128 classes set the sweep time)
 #define PMDI_DL_LDS 128     // distinct-chosen-cluster entries kept in LDS (fallback path)
 
 enum { K_GAUSSIAN = 0, K_CATEGORICAL = 1, K_NEGBINOM = 2 };
@@ -108,6 +108,8 @@ struct SweepArgs {
     double *xinc;               // [chain][2][K][P] log-weight increment per particle (by parity of the swept observation)
     int *xlab;                  // [chain][2][K][P] chosen label per particle
     unsigned long long *xhdr;   // [chain][2][K][2] per-step header: flags / labels, increment of class slot 0
+    unsigned *start_sig;        // every workgroup of this launch adds 1 on entry (signal memory), or null: the other launches of a sweep
+                                // wait for the heaviest chains' workgroups to have been placed (a whole CU each) before they start
     int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
     int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
 };

@@ -1189,6 +1189,8 @@ template <int T, int WPS, bool K1>
 __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__restrict__ ap)
 {
     PMDI_PREAMBLE_K(K1);
+    if (a.start_sig && tid == 0 && (!a.ksplit || bslot < a.n_slots))
+        __hip_atomic_fetch_add(a.start_sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (bslot >= a.n_slots) return;            // padding of a split launch (chain slots are dealt in groups of eight)
     // two launches share the chains of a sweep (heavy: wide workgroups, light: narrow ones)
     if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || bslot < a.rank_lo || bslot >= a.rank_hi)) return;
