@@ -45,6 +45,13 @@ def build(force=False, verbose=False):
     extra = os.environ.get("PMDI_EXTRA_HIPCC_FLAGS", "").split()
     bdir = os.path.join(_PKG, "build" if not os.environ.get("PMDI_LIB_PATH") else "build_ab")
     os.makedirs(bdir, exist_ok=True)
+    import fcntl
+    with open(os.path.join(bdir, ".lock"), "w") as lock:      # ranks of one node may call build() at the same moment
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(force, verbose, hipcc, extra, bdir)
+
+
+def _build_locked(force, verbose, hipcc, extra, bdir):
     hdr_time = max(os.path.getmtime(p) for p in _HEADERS)
     stamp = os.path.join(bdir, "flags.txt")
     flags_now = " ".join(extra)
