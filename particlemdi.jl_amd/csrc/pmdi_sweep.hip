@@ -544,6 +544,62 @@ __device__ __forceinline__ void stats_update_all(const DsetDev &d, const KS &s, 
     }
 }
 
+// Burn-in (the class x label items outgrow the LDS tables): every live cluster is evaluated, as the reference does
+// (src/pmdi.jl:218-220).  There are hundreds to thousands of them, so the lanes are the CLUSTERS: each lane walks its
+// cluster's features in order (the same terms added in the same order as the staged form of the fast path), four pool
+// reads in flight.  (Staging the terms in LDS allowed 10 clusters per round at D = 200: the ordered sums of 2 600 clusters
+// took 3.3 M cycles per step, 63 % of cfg5's first sweep.)  Out of line: its registers are not the step loop's.
+template <int T>
+__device__ __noinline__ void sweep_logprob_all(const SweepArgs *__restrict__ ap, int k, int maxid)
+{
+    PMDI_PREAMBLE;
+    const DsetDev &d = dsb[k];
+    const KS s = make_ks(d, chain);
+    const int D = d.D;
+    const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
+    const int nflag = sh.knflag[k];
+    for (int j0 = 0; j0 < maxid; j0 += T) {
+        const int id = 1 + j0 + tid;
+        if (id <= maxid) {
+            const int cn = s.cn[id];
+            double out;
+            if (d.kind == K_GAUSSIAN) {
+                out = (double)nflag * glob(d.gtab)[cn];
+                for (int q0 = 0; q0 < D; q0 += 4) {
+                    double2 sb4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sb4[u] = ld2(s.sb, (size_t)id * D + min(q0 + u, D - 1));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = q0 + u;
+                        if (q < D && flk[q]) {
+                            double ta, tb;
+                            gauss_terms(sh.xs[q], (double)cn, gauss_ml(cn, sb4[u]), ta, tb);
+                            out += ta; out -= tb;
+                        }
+                    }
+                }
+            } else if (d.kind == K_CATEGORICAL) {
+                double acc = 0.0;                                  // categorical_cluster.jl:30
+                for (int q = 0; q < D; ++q) if (flk[q]) acc += glob(d.lhtab)[glob(d.maxcol)[q] + 2 * cn];
+                out = -acc;
+                for (int q = 0; q < D; ++q)
+                    if (flk[q]) {
+                        const int x = ((const int *)sh.xs)[q];
+                        const int c = s.cnt[((size_t)id * D + q) * d.L + (x - 1)];
+                        out += (cn == 0) ? glob(d.lhtab)[1] : glob(d.lhtab)[2 * c + 1];
+                    }
+            } else {
+                out = 0.0;                                         // negbinom_cluster.jl:25
+                for (int q = 0; q < D; ++q)
+                    if (flk[q]) out += negbin_term(glob(d.lgtab), cn, ((const int *)sh.xs)[q], s.nbs[(size_t)id * D + q]);
+            }
+            s.lp[id] = out;
+        }
+    }
+    __syncthreads();
+}
+
 // One (observation, dataset) step on the fallback path: per-particle class keys, ballot scans,
 // per-id tables in global memory.  `converted`: the fast path already drew the allocations but
 // its LDS census overflowed.  Results (clones, classes, pool overflow) go back through sh.misc.
@@ -1308,7 +1364,10 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // -- A2/A3: log-predictive of the needed clusters.  Lanes = (cluster, feature) for
             // the per-feature terms, then one lane per cluster adds them in feature order
             // (bit-identical to the sequential loops of calc_logprob).
-            {
+            if (!small) {
+                PH(2); FRESH_LANE_IDS();
+                sweep_logprob_all<T>(ap, k, maxid);
+            } else {
                 const int RS = 2 * D + 1, D1 = D + 1;
                 int CH = a.terms_cap / RS;
                 if (CH < 1) CH = 1;

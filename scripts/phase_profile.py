@@ -1,5 +1,5 @@
 """Per-phase shader-clock totals (lane 0 of the chain's workgroup 0) of the last sweep of a few chains.
-usage: PMDI_PHASE_TIMERS=1 python scripts/phase_profile.py WORKLOAD CHAINS ITERS"""
+usage: PMDI_PHASE_TIMERS=1 python scripts/phase_profile.py WORKLOAD CHAINS ITERS [SCALE]"""
 import os, sys
 import numpy as np
 os.environ.setdefault("PMDI_PHASE_TIMERS", "1")
@@ -8,7 +8,7 @@ import __graft_entry__ as G
 G.build(); pkg = G.load_package()
 from particlemdi_jl_amd import workloads
 name, C, iters = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-w = workloads.make(name)
+w = workloads.make(name, float(sys.argv[4]) if len(sys.argv) > 4 else 1.0)
 sw = pkg.Sweeper(w["data"], w["kinds"], w["N"], w["P"], n_chains=C, seed=41)
 g = pkg.Gibbs(sw, rho=0.25, feature_select=(name == "cfg5"))
 g.iterate(iters); st = g.results()["stats"]
