@@ -154,8 +154,8 @@ def test_baseline_configs_reduced_vs_oracle(pkg, O, cfg, scale, P):
 
 # burn-in iterations on the device before the compared one (a mid-chain state: tens of live clusters, resampling active).
 # cfg5 starts from the planted clustering with 5 % of the labels scrambled instead of the random start of
-# src/pmdi.jl:63-66: its first sweeps from a random start (hundreds of particle classes at P = 4 096, N = 50) take
-# minutes each, which the GPU test budget does not have.
+# src/pmdi.jl:63-66: its first sweep from a random start (thousands of live clusters at P = 4 096, N = 50) costs the
+# oracle minutes, which the GPU test budget does not have.
 FULL = {"cfg3": 3, "HL": 3, "cfg4": 2, "cfg5": 1}
 
 
