@@ -1999,6 +1999,19 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             for (int p = tid; p < P; p += T) { const double w = exp(sh.lw[p] - mx); sa += w; sb2 += w * w; }
             block_sum2<T>(sa, sb2, gen(sh.red));
             ess = (sa * sa) / sb2;
+            // The tree-ordered sums agree with calc_ESS's sequential loop (src/misc.jl:19-23) to ~1e-13 relative; the decision
+            // below is a comparison, so when ESS lands that close to P/2 -- k equal weights and the rest negligible give exactly k in
+            // the reference's order, and k = P/2 does happen -- the sums are redone in the reference's order by one lane.
+            if (fabs(ess - 0.5 * (double)P) <= 1e-9 * (double)P) {
+                __syncthreads();
+                if (tid == 0) {
+                    double na = 0.0, nb = 0.0;
+                    for (int p = 0; p < P; ++p) { const double w = exp(sh.lw[p] - mx); na += w; nb += w * w; }
+                    sh.red[40] = (na * na) / nb;
+                }
+                __syncthreads();
+                ess = sh.red[40];
+            }
             resample = ess <= 0.5 * (double)P;            // src/pmdi.jl:317
         }
 

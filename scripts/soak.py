@@ -72,6 +72,11 @@ def _one_case(rng):
                 r["stats"][c][key] == o["stats"][key] for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")) \
                 and np.allclose(r["logweight"][c], o["logweight"], rtol=1e-9, atol=1e-9)
             if not ok:
+                os.makedirs("gpurun_out", exist_ok=True)
+                np.savez("gpurun_out/soak_fail.npz", kinds=np.array(kinds), N=N, P=P, Cn=Cn, q1=q1, q2=q2, block=block, n1=n1, it=it, chain=c, seed=seed,
+                         s=s, order=order, Pi=np.stack([h[0] for h in hyp]), Phi=np.stack([h[1] for h in hyp]),
+                         flags=np.zeros(0) if flags is None else flags, env=np.array([os.environ["PMDI_LIGHT_IDS"], os.environ["PMDI_VERY_HEAVY"], os.environ["PMDI_KSPLIT"]]),
+                         **{f"data{k}": d for k, d in enumerate(data)})
                 raise AssertionError(f"MISMATCH: {desc} iteration {it} chain {c}")
         s = r["s"].copy()
     for o in orc: o.close()

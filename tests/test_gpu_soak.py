@@ -8,9 +8,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_random_configurations_equal_the_oracle(pkg, O):
+def _soak():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak.py")
     spec = importlib.util.spec_from_file_location("pmdi_soak", path)
     soak = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(soak)
-    assert soak.run(60.0, 2024, max_cases=150, verbose=False) >= 20
+    return soak
+
+
+def test_random_configurations_equal_the_oracle(pkg, O):
+    assert _soak().run(60.0, 2024, max_cases=150, verbose=False) >= 20
+
+
+def test_resampling_decision_at_an_exact_tie(pkg, O):
+    """Seed 7's 31st configuration (K = 2, N = 3, P = 8, Q1 corrected mode) reaches ESS == P/2 exactly -- four equal
+    weights, four negligible ones: the reference's sequential sums give exactly 4.0 and resample (src/pmdi.jl:317 is <=);
+    tree-ordered sums gave 4.000000000000001 and did not.  The kernel redoes the sums in the reference's order whenever
+    ESS is within 1e-9 P of the threshold."""
+    assert _soak().run(60.0, 7, max_cases=40, verbose=False) == 40
