@@ -1133,7 +1133,9 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 if (!lm) for (int id = 1 + tid; id <= oldmax; id += T) { s.ncop[id] = 0; s.firstc[id] = PMDI_INF_I; }
                 __syncthreads();
                 PHR(8);   // moves
-                const int nc2 = rebuild_classes<T>(pidk, cl, sh, P);
+                // one class before the resampling = one class after it (same value, particle 0 still its lowest member: slot 0 keeps
+                // ancestor 0): the class list stands as it is
+                const int nc2 = (sh.kncls[k] == 1) ? 1 : rebuild_classes<T>(pidk, cl, sh, P);
                 if (tid == 0) {
                     sh.kmaxid[k] = newmax; sh.kncls[k] = nc2; sh.kcur[k] = cur ^ 1;
                     sh.wk[k * 8 + WK_MOVED] += sh.misc[M_MOVED]; sh.wk[k * 8 + WK_MOVE_EVENTS] += moves ? 1 : 0;
