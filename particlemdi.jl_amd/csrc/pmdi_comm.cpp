@@ -40,12 +40,13 @@ Rccl g_rccl;
 int load_rccl()
 {
     if (g_rccl.lib) return 0;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
-    for (const char *nm : names) {
-        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    for (const char *nm : names) {          // a copy the process has already mapped (e.g. the one PyTorch ships) is the one to share
+        lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD);
         if (lib) break;
     }
+    for (int i = 0; i < 3 && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return pmdi_set_error(PMDI_E_DEVICE, "RCCL is not available: %s", dlerror());
     Rccl r;
     r.lib = lib;
