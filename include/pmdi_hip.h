@@ -103,7 +103,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
  *   PMDI_KSPLIT=0/1       K > 1: one workgroup per chain (throughput form) / K cooperating workgroups per chain, one per
  *                         dataset, meeting once per swept observation (latency form).  Default: split while n_chains * K
  *                         workgroups are resident at once.  pmdi_is_split() tells which form a handle uses.
- *   PMDI_LDS_TARGET       LDS bytes per workgroup above which the per-particle tables move to global memory */
+ *   PMDI_LDS_TARGET       LDS bytes per workgroup above which the per-particle tables move to global memory
+ *   PMDI_START_GATE=0     do not hold the heavy / light launches of a sweep until the heaviest chains' workgroups have been
+ *                         placed (switched off by itself under rocprofv3: counter collection serialises the queues) */
 int pmdi_destroy(pmdi_handle *h);
 const char *pmdi_last_error(void);
 int pmdi_abi_version(void);

@@ -506,7 +506,11 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             h->very_heavy = (h->T == 512 && h->two_per_cu) ? env_int("PMDI_VERY_HEAVY", 128) : 0;
             int can_wait = 0;
             (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, cfg->device);
-            if (h->very_heavy > 0 && can_wait && env_int("PMDI_START_GATE", 1) != 0) {
+            // (not under a profiler that collects counters: rocprofv3 --pmc runs the kernels of all queues one at a time, and a launch
+            // that waits for another launch's workgroups then never starts -- observed as a hang of the FETCH_SIZE pass)
+            auto env_has = [](const char *name, const char *what) { const char *v = getenv(name); return v && strstr(v, what) != nullptr; };
+            const bool profiled = env_has("LD_PRELOAD", "rocprof") || env_has("ROCP_TOOL_LIBRARIES", "rocprof") || env_has("HSA_TOOLS_LIB", "rocprof");
+            if (h->very_heavy > 0 && can_wait && !profiled && env_int("PMDI_START_GATE", 1) != 0) {
                 void *sig = nullptr;
                 if (hipExtMallocWithFlags(&sig, 8, hipMallocSignalMemory) == hipSuccess) {
                     h->start_sig = (unsigned *)sig; h->owned.push_back(sig);
