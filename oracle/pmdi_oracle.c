@@ -374,6 +374,7 @@ struct pmdi_oracle {
     uint8_t *sstar;         /* [k][i][p]  = sstar[p,i,k], src/pmdi.jl:146 */
     int64_t *maxid;         /* [k] running maximum(particle_k) */
     int64_t last_updates[8], last_moved[8];   /* per dataset, last sweep: cluster_add! calls at :300, deepcopies at :336 */
+    int64_t *dbg_cols;      /* analysis only (scripts/column_stats.py): [step][k] distinct columns of particle[:, :, k] before the ESS test */
     /* scratch */
     int64_t *partstar, *tmp_i64, *idmap;
     double  *tmp_d;
@@ -724,6 +725,28 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                 }
         }
 
+        if (h->dbg_cols) {
+            /* distinct columns particle[:, p, k] over the particles: sort the columns' 64-bit hashes (analysis only) */
+            for (int k = 0; k < K; ++k) {
+                const int64_t *particle = h->particle + (int64_t)k * P * N;
+                uint64_t *hs = (uint64_t *)h->tmp_d;          /* P doubles = P hashes */
+                for (int p = 0; p < P; ++p) {
+                    uint64_t x = 1469598103934665603ull;
+                    for (int nn = 0; nn < N; ++nn) { x ^= (uint64_t)particle[(int64_t)p * N + nn]; x *= 1099511628211ull; x ^= x >> 29; }
+                    hs[p] = x;
+                }
+                int64_t nc = 0;
+                for (int p = 0; p < P; ++p) {                 /* insertion into the sorted distinct prefix: fine for the small counts of interest */
+                    int64_t lo = 0, hi = nc;
+                    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (hs[mid] < hs[p]) lo = mid + 1; else hi = mid; }
+                    if (lo < nc && hs[lo] == hs[p]) continue;
+                    uint64_t v = hs[p];
+                    memmove(hs + lo + 1, hs + lo, (size_t)(nc - lo) * sizeof(uint64_t));
+                    hs[lo] = v; nc += 1;
+                }
+                h->dbg_cols[(pos - (n1 - 1)) * K + k] = nc;
+            }
+        }
         double ess = pmdi_oracle_calc_ess(logweight, P);
         int resampled = 0;
         if (ess <= 0.5 * (double)P) {                 /* :317 */
@@ -845,6 +868,8 @@ int pmdi_oracle_feature_select(pmdi_oracle *h, int64_t iter, const int64_t *s_tr
     }
     return 0;
 }
+
+void pmdi_oracle_debug_columns(pmdi_oracle *h, int64_t *buf) { h->dbg_cols = buf; }
 
 int pmdi_oracle_export(const pmdi_oracle *h, int64_t *particle, int64_t *counts,
                        int64_t *cluster_n, int64_t *max_id)

@@ -84,6 +84,8 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
     if (sweep_state) {
         d.o_particle[0] = take((size_t)N * P * 4);
         d.o_particle[1] = take((size_t)N * P * 4);
+        d.o_col = take((size_t)P * 4);
+        d.o_cgrp = take((size_t)N * P * 8);
         d.o_pid = take((size_t)P * 4);
         d.o_sid = take((size_t)P * 4);
         d.o_kv = take((size_t)P * 4);
@@ -756,15 +758,19 @@ int pmdi_export_state(pmdi_handle *h, int32_t chain, int64_t *particle, int64_t 
     HIP_TRY(hipStreamSynchronize(h->stream));
     std::vector<int> ks((size_t)PMDI_KMAX_I * 2);
     HIP_TRY(hipMemcpy(ks.data(), (char *)h->d_kstate.p + (size_t)chain * PMDI_KMAX_I * 2 * 4, ks.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<int> tmp((size_t)N * P), tc((size_t)cap + 1);
+    std::vector<int> tmp((size_t)N * P), tc((size_t)cap + 1), col((size_t)P);
     for (int k = 0; k < K; ++k) {
         const DsetDev &d = h->ds[k];
         const char *base = d.arena + (size_t)chain * d.stride;
         const int cur = ks[(size_t)k * 2 + 1];
         if (particle) {
+            // the device keeps the distinct columns of particle[:, :, k] and a column index per particle
             HIP_TRY(hipMemcpy(tmp.data(), base + d.o_particle[cur], tmp.size() * 4, hipMemcpyDeviceToHost));
-            for (int p = 0; p < P; ++p)                               // particle[n, p, k], column-major
-                for (int nn = 0; nn < N; ++nn) particle[((size_t)k * P + p) * N + nn] = tmp[(size_t)nn * P + p];
+            HIP_TRY(hipMemcpy(col.data(), base + d.o_col, col.size() * 4, hipMemcpyDeviceToHost));
+            for (int p = 0; p < P; ++p) {                             // particle[n, p, k], column-major
+                if (col[p] < 0 || col[p] >= P) return fail(PMDI_E_STATE, "corrupt column index %d of particle %d", col[p], p);
+                for (int nn = 0; nn < N; ++nn) particle[((size_t)k * P + p) * N + nn] = tmp[(size_t)col[p] * N + nn];
+            }
         }
         if (counts) {
             HIP_TRY(hipMemcpy(tc.data(), base + d.o_counts, tc.size() * 4, hipMemcpyDeviceToHost));

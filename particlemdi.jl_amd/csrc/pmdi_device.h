@@ -48,7 +48,8 @@ __device__ __forceinline__ void st2(PMDI_GLOBAL dbl2v *p, size_t i, double2 v) {
 
 struct KS {  // pointers of one (chain, dataset)
     gint part[2];
-    gint pid, sid, kv, newid, counts, ncop, firstc, cn, clslead, clsval, dl;
+    gint pid, sid, kv, newid, counts, ncop, firstc, cn, clslead, clsval, dl, col;
+    PMDI_GLOBAL unsigned long long *cgrp;
     gdbl lp, cdf;
     gdbl2 ml, sb;
     gint cnt;
@@ -62,6 +63,8 @@ __device__ __forceinline__ KS make_ks(const DsetDev &d, int chain)
     char *b = d.arena + (size_t)chain * d.stride;
     s.part[0] = glob((int *)(b + d.o_particle[0]));
     s.part[1] = glob((int *)(b + d.o_particle[1]));
+    s.col = glob((int *)(b + d.o_col));
+    s.cgrp = glob((unsigned long long *)(b + d.o_cgrp));
     s.pid = glob((int *)(b + d.o_pid));
     s.sid = glob((int *)(b + d.o_sid));
     s.kv = glob((int *)(b + d.o_kv));

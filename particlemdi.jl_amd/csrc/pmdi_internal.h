@@ -24,8 +24,9 @@ enum { SITE_DRAW = 0, SITE_RESAMPLE_U = 1, SITE_RESAMPLE_SLOT = 2, SITE_PSTAR = 
 enum { ST_NOPS = 0, ST_NRESAMPLE = 1, ST_NCLONES = 2, ST_MAXID = 3, ST_SUMCLASSES = 4 };
 // work counters per (chain, dataset), 8 slots each: clusters whose log-predictive was evaluated, distinct clusters
 // updated (deepcopy + cluster_add!), of which cloned, cluster ids moved down by the renumbering of a resampling event,
-// resampling events that moved any id
-enum { WK_EVAL = 0, WK_UPD = 1, WK_CLONE = 2, WK_MOVED = 3, WK_MOVE_EVENTS = 4 };
+// resampling events that moved any id, distinct columns of the particle -> cluster table met by the resampling events (summed),
+// columns created by copy-on-write splits
+enum { WK_EVAL = 0, WK_UPD = 1, WK_CLONE = 2, WK_MOVED = 3, WK_MOVE_EVENTS = 4, WK_COLS = 5, WK_SPLITS = 6 };
 
 // One dataset as the kernels see it.  Data are row-major on the device so
 // that an observation row is one contiguous, coalesced read.
@@ -45,7 +46,10 @@ struct DsetDev {
     // per-(chain, dataset) state arena: chain c lives at arena + c*stride
     char *arena;
     size_t stride;
-    size_t o_particle[2];   // int  [N][P]  label -> cluster id (1-based), double buffered
+    size_t o_particle[2];   // int  [P][N]  the DISTINCT columns of particle[:, p, k] (label -> cluster id, 1-based): column c at
+                            //              [c*N, c*N + N); columns 0..ncol-1 are live; double buffered (a resampling event compacts)
+    size_t o_col;           // int  [P]     column of each particle
+    size_t o_cgrp;          // u64  [P][N]  scratch of the copy-on-write split, keyed (column, label): (step << 32) | group's column
     size_t o_pid;           // int  [P]     class of each particle (particle_id)
     size_t o_sid;           // int  [P]     sstar_id
     size_t o_kv;            // int  [P]     per-particle scratch (class-key value), used when not in LDS

@@ -115,7 +115,7 @@ __device__ __forceinline__ void lds_barrier()
 struct Carve {  // byte offsets of the LDS arrays (shared by host sizing and the kernel)
     size_t xs, pis, lw, term, lpl, cdf, scan, red, pid, sid, kv, lead_of, slot_of, cl_lead, cl_val,
         need, need_slot, item_id, dl, dl_slot, h1k, h1a, h2k, h2a, h2b, ktab_minp, ktab_val, klist, kl_v, wk,
-        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, misc, ph, stat,
+        kl_key, fl_p, fl_slot, fl_nnew, fl_tgt, bm_fresh, bm_clone, bm_keep, bm_reuse, col, kncol, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, kmaxid, kncls, kcur, knflag, khint, misc, ph, stat,
         fl, news, total;
 };
 
@@ -140,6 +140,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.kcur = take(PMDI_KMAX_I * 4);
     c.knflag = take(PMDI_KMAX_I * 4);
     c.khint = take(PMDI_KMAX_I * 4);
+    c.kncol = take(PMDI_KMAX_I * 4);
     c.leaf_i1 = take(64 * 4);
     c.leaf_n = take(64 * 4);
     c.leaf_tot = take(64 * 8);
@@ -176,6 +177,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.term = take((size_t)a.terms_cap * 8);
     c.lw = take((size_t)a.P * 8);
     c.pid = take(a.pid_lds ? (size_t)KL * a.P * 4 : 0);
+    c.col = take(a.pid_lds ? (size_t)KL * a.P * 4 : 0);
     c.sid = take(a.pp_lds ? (size_t)a.P * 4 : 0);
     c.kv = take(a.pp_lds ? (size_t)a.P * 4 : 0);
     c.lead_of = take((size_t)(a.P + 1) * 4);
@@ -184,6 +186,8 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.cl_val = take((size_t)KL * PMDI_CLS_LDS * 4);
     c.bm_fresh = take((size_t)((a.P >> 6) + 1) * 8);
     c.bm_clone = take((size_t)((a.P >> 6) + 1) * 8);
+    c.bm_keep = take((size_t)((a.P >> 6) + 1) * 8);
+    c.bm_reuse = take((size_t)((a.P >> 6) + 1) * 8);
     c.fl = take((size_t)KL * Dp);
     c.news = take((size_t)KL * a.P);
     c.total = o;
@@ -192,14 +196,14 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
 struct Sh {
     ldbl xs, pis, lw, term, lpl, cdf, red;
     lu64 scan;
-    lint pid, sid, kv, lead_of, slot_of, cl_lead, cl_val, need, need_slot, item_id, dl, dl_slot;
+    lint pid, col, sid, kv, lead_of, slot_of, cl_lead, cl_val, need, need_slot, item_id, dl, dl_slot;
     HT h1, h2;
     lint ktab_minp, ktab_val, klist, kl_v, kl_key, fl_p, fl_slot, fl_nnew, fl_tgt;
-    lu32 bm_fresh, bm_clone;
+    lu32 bm_fresh, bm_clone, bm_keep, bm_reuse;
     lint leaf_i1, leaf_n;
     ldbl leaf_tot, leaf_carry;
     lu8 leaf_prog;
-    lint kmaxid, kncls, kcur, knflag, khint, lab, misc;
+    lint kmaxid, kncls, kcur, knflag, khint, kncol, lab, misc;
     li64 ph, stat;   // phase timers; the sweep's counters (n_operations, ...), kept by lane 0
     li64 wk;         // work counters per dataset (WK_*), kept by lane 0: what the dedup-aware byte model of bench.py is built from
     lu8 fl, news;
@@ -320,7 +324,7 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
         sh.xs = (ldbl)(smem + c.xs); sh.pis = (ldbl)(smem + c.pis); sh.lw = (ldbl)(smem + c.lw);
         sh.term = (ldbl)(smem + c.term); sh.lpl = (ldbl)(smem + c.lpl); sh.cdf = (ldbl)(smem + c.cdf);
         sh.scan = (lu64)(smem + c.scan); sh.red = (ldbl)(smem + c.red);
-        sh.pid = (lint)(smem + c.pid); sh.sid = (lint)(smem + c.sid); sh.kv = (lint)(smem + c.kv);
+        sh.pid = (lint)(smem + c.pid); sh.col = (lint)(smem + c.col); sh.sid = (lint)(smem + c.sid); sh.kv = (lint)(smem + c.kv);
         sh.lead_of = (lint)(smem + c.lead_of); sh.slot_of = (lint)(smem + c.slot_of);
         sh.cl_lead = (lint)(smem + c.cl_lead); sh.cl_val = (lint)(smem + c.cl_val);
         sh.need = (lint)(smem + c.need); sh.need_slot = (lint)(smem + c.need_slot);
@@ -332,9 +336,10 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
         sh.fl_p = (lint)(smem + c.fl_p); sh.fl_slot = (lint)(smem + c.fl_slot); sh.fl_nnew = (lint)(smem + c.fl_nnew);
         sh.fl_tgt = (lint)(smem + c.fl_tgt);
         sh.bm_fresh = (lu32)(smem + c.bm_fresh); sh.bm_clone = (lu32)(smem + c.bm_clone);
+        sh.bm_keep = (lu32)(smem + c.bm_keep); sh.bm_reuse = (lu32)(smem + c.bm_reuse);
         sh.leaf_i1 = (lint)(smem + c.leaf_i1); sh.leaf_n = (lint)(smem + c.leaf_n);
         sh.leaf_tot = (ldbl)(smem + c.leaf_tot); sh.leaf_carry = (ldbl)(smem + c.leaf_carry); sh.leaf_prog = (lu8)(smem + c.leaf_prog);
-        sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag); sh.khint = (lint)(smem + c.khint);
+        sh.kmaxid = (lint)(smem + c.kmaxid); sh.kncls = (lint)(smem + c.kncls); sh.kcur = (lint)(smem + c.kcur); sh.knflag = (lint)(smem + c.knflag); sh.khint = (lint)(smem + c.khint); sh.kncol = (lint)(smem + c.kncol);
         sh.lab = (lint)(smem + c.term); sh.misc = (lint)(smem + c.misc); sh.ph = (li64)(smem + c.ph); sh.stat = (li64)(smem + c.stat);
         sh.wk = (li64)(smem + c.wk);
         sh.fl = (lu8)(smem + c.fl); sh.news = (lu8)(smem + c.news);
@@ -387,10 +392,12 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         const KS s = make_ks(d, chain);
         const int D = d.D;
         const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+        const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
         unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
         for (int idx = tid; idx <= cap; idx += T) { s.counts[idx] = 0; s.ncop[idx] = 0; s.firstc[idx] = PMDI_INF_I; }
-        for (int idx = tid; idx < N * P; idx += T) { s.newid[idx] = 0; s.part[0][idx] = 1; }
-        for (int p = tid; p < P; p += T) pidk[p] = 1;
+        for (int idx = tid; idx < N * P; idx += T) { s.newid[idx] = 0; s.cgrp[idx] = 0; }
+        // every particle starts on the same column of particle[:, :, k] (:169-171): one column is stored
+        for (int p = tid; p < P; p += T) { pidk[p] = 1; colk[p] = 0; }
         for (int u = tid; u < 256; u += T) { sh.lab[u] = PMDI_INF_I; sh.lab[256 + u] = 0; sh.lab[512 + u] = 0; }
         for (int q = tid; q < D; q += T) flk[q] = flags ? flags[d.flag_off + q] : (unsigned char)1;
         for (int nn = tid; nn < N; nn += T) sh.pis[k * N + nn] = Pi[(size_t)k * N + nn];
@@ -414,9 +421,9 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         int nu = 0;
         for (int v = 0; v < N; ++v) nu += (sh.lab[v] != PMDI_INF_I) ? 1 : 0;
         // particle[u, :, k] .= id ; counts (:195-198)
-        for (int idx = tid; idx < N * P; idx += T) {
-            const int id = sh.lab[256 + idx / P];
-            if (id) s.part[0][idx] = id;
+        for (int nn = tid; nn < N; nn += T) {
+            const int id = sh.lab[256 + nn];
+            s.part[0][nn] = id ? id : 1;
         }
         if (tid < N && sh.lab[256 + tid]) s.counts[sh.lab[256 + tid]] = P;
         if (tid == 0) { s.counts[1] = P * N - nu * P; s.cn[1] = 0; }
@@ -469,6 +476,7 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
             sh.kmaxid[k] = nu + 1;
             sh.kncls[k] = 1;
             sh.kcur[k] = 0;
+            sh.kncol[k] = 1;
             int nf = 0;
             for (int q = 0; q < D; ++q) nf += flk[q];
             sh.knflag[k] = nf;
@@ -542,6 +550,93 @@ __device__ __forceinline__ void stats_update_all(const DsetDev &d, const KS &s, 
         item(j, src, dst, nnew);
         stats_update_one(d, s, flk[q], xs, src, dst, nnew, D, q);
     }
+}
+
+// The particle -> cluster table particle[:, :, k] (N x P, src/pmdi.jl:131) is kept by DISTINCT COLUMN: tab[c*N + label] for the
+// live columns c = 0..ncol-1 and a column index per particle.  A settled chain holds about ten distinct columns for its 1 024
+// particles (scripts/column_stats.py), so what the reference does per particle -- the gather particle[:, partstar, k] of every
+// resampling event (:322), the relabelling (:331-337), the remap of a cloned label (:301-308) -- is done per column.  The
+// column numbering is internal: results do not depend on it.
+//
+// columns_apply = the copy-on-write remap `particle[s_id, part, k] = id` (:301-308) of one step.  wr(p, c, tgt) names particle p's
+// chosen cluster c and the id it is updated under (tgt != c: it was cloned, the particle's table entry under its new label
+// changes).  Particles of one column that chose the same label move together: such a group takes a copy of the column with
+// that entry replaced -- or the column itself when nobody else stays on it (no particle that does not write, and the first
+// group to ask).  Every live column keeps at least one particle, so there are never more than P of them.
+template <int T, class Wr>
+__device__ __forceinline__ void columns_apply(const Sh &sh, const KS &s, gint tab, const Dual<int> &colk, int k, int N, int P, int tid_,
+                                              unsigned epoch, Wr wr)
+{
+    const int tid = tid_;
+    const int ncol0 = sh.kncol[k];
+    const int nbw = 2 * ((P >> 6) + 1);                       // 32-bit words of a bitmap
+    int anyw = 0;
+    for (int pb = 0; pb < P; pb += T) {                       // which columns keep a particle that does not write?
+        const int p = pb + tid;
+        const bool valid = p < P;
+        int c = 0, tgt = 0, cl = 0;
+        if (valid) { wr(p, c, tgt); cl = colk[p]; }
+        const bool w = valid && tgt != c;
+        anyw |= w ? 1 : 0;
+        int cnt;
+        if (wave_group(cl, valid && !w, cnt)) atomicOr(gen(&sh.bm_keep[cl >> 5]), 1u << (cl & 31));
+    }
+    if (!__syncthreads_or(anyw)) {                             // nothing was cloned: the table stands
+        for (int e = tid; e < nbw; e += T) sh.bm_keep[e] = 0;
+        return;
+    }
+    // One owner per (column, label) group makes the group's column.  The scratch entry of a key carries the step it was
+    // claimed in (its epoch, unique within the sweep and the dataset), so nothing has to be cleared between steps.
+    const unsigned long long etag = (unsigned long long)epoch << 32;
+    for (int pb = 0; pb < P; pb += T) {
+        const int p = pb + tid;
+        const bool valid = p < P;
+        int c = 0, tgt = 0, cl = 0, ns = 0;
+        if (valid) { wr(p, c, tgt); cl = colk[p]; ns = sh.news[k * P + p]; }
+        const bool w = valid && tgt != c;
+        const int key = cl * N + ns;
+        int cnt;
+        if (wave_group(key, w, cnt)) {
+            unsigned long long *e = gen(s.cgrp + key);
+            const unsigned long long old = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old >> 32) != epoch && atomicCAS(e, old, etag) == old) {
+                const unsigned bit = 1u << (cl & 31);
+                const bool keep = (sh.bm_keep[cl >> 5] & bit) != 0;
+                const bool inplace = !keep && !(atomicOr(gen(&sh.bm_reuse[cl >> 5]), bit) & bit);
+                int newc = cl;
+                if (!inplace) {                                // the originals are read here; in-place entries are written after the barrier
+                    newc = atomicAdd(gen(&sh.kncol[k]), 1);
+                    if (newc < P) {
+                        for (int nn = 0; nn < N; nn += 4) {
+                            int v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = (nn + u < N) ? tab[(size_t)cl * N + nn + u] : 0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (nn + u < N) tab[(size_t)newc * N + nn + u] = (nn + u == ns) ? tgt : v[u];
+                        }
+                    }
+                }
+                __hip_atomic_store(e, etag | (unsigned long long)(unsigned)(inplace ? ((cl + 1) | 0x40000000) : (newc + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();
+    for (int pb = 0; pb < P; pb += T) {
+        const int p = pb + tid;
+        if (p < P) {
+            int c, tgt;
+            wr(p, c, tgt);
+            if (tgt != c) {
+                const int cl = colk[p], ns = sh.news[k * P + p];
+                const unsigned v = (unsigned)__hip_atomic_load(gen(s.cgrp + (cl * N + ns)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (sc1: from L2, where the owner's CAS and store went)
+                if (v & 0x40000000u) tab[(size_t)cl * N + ns] = tgt;      // the group kept its column: every member writes the same value
+                colk[p] = (int)(v & 0x3fffffffu) - 1;
+            }
+        }
+    }
+    for (int e = tid; e < nbw; e += T) { sh.bm_keep[e] = 0; sh.bm_reuse[e] = 0; }
+    if (tid == 0) sh.wk[k * 8 + WK_SPLITS] += sh.kncol[k] - ncol0;
+    // (the caller's next barrier orders these writes before the next step's reads)
 }
 
 // Burn-in (the class x label items outgrow the LDS tables): every live cluster is evaluated, as the reference does
@@ -621,6 +716,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     const int D = d.D;
     const gint part = s.part[sh.kcur[k]];
     const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+    const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
     const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
     const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
     const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
@@ -641,7 +737,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         if (valid) {
                             const int ns = sh.news[k * P + p];
                             key = (pidk[p] - 1) * N + ns;
-                            c = part[ns * P + p];
+                            c = part[(size_t)colk[p] * N + ns];
                             const int v = s.newid[key];
                             sidp[p] = c;
                             kvp[p] = v;
@@ -682,7 +778,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                                 __hip_atomic_store(a.xlab + xo, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                             key = (cls - 1) * N + ns;
-                            c = part[ns * P + p];                        // sstar_id (:264)
+                            c = part[(size_t)colk[p] * N + ns];          // sstar_id (:264)
                             const int v = s.newid[key];
                             sidp[p] = c;
                             kvp[p] = v;
@@ -762,6 +858,10 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
 
                 PHS(7);
                 // -- E: apply: new class ids, remap cloned labels (:301-308)
+                columns_apply<T>(sh, s, part, colk, k, N, P, tid, (unsigned)(pos - (n1 - 1)) + 1u, [&](int p, int &c, int &tgt) {
+                    c = sidp[p];
+                    tgt = gcensus ? s.ncop[c] : sh.h2.a[ht_find(sh.h2, c)];
+                });
                 for (int pb = 0; pb < P; pb += T) {
                     const int p = pb + tid;
                     const bool valid = p < P;
@@ -771,9 +871,6 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         const int key = (pidk[p] - 1) * N + ns;
                         const int v = kvp[p];
                         newcls = (v <= 0) ? s.newid[key] : v;
-                        const int c = sidp[p];
-                        const int tgt = gcensus ? s.ncop[c] : sh.h2.a[ht_find(sh.h2, c)];
-                        if (tgt != c) part[ns * P + p] = tgt;
                         pidk[p] = newcls;
                         kvp[p] = key;
                     }
@@ -971,57 +1068,57 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
                 const gcint src = s.part[cur];
                 const gint dst = s.part[cur ^ 1];
-                // Occupancy of every old id after the gather, then old id -> new id, in LDS (the term buffer and the hash / list
-                // tables are idle here) when the ids fit; otherwise the per-id scratch tables in global memory.  The new counts
-                // (:338) are the old ids' occupancies carried over to their new numbers: the histogram is taken while the gathered
-                // entries are in registers, so the second pass over the N x P table only exists to rewrite ids that moved, and is
-                // skipped when the live ids are exactly 1..U' already.
+                const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
+                const int ncol_old = sh.kncol[k];
+                // The gather particle[:, partstar, k] (:322) by column: a particle takes its ancestor's column INDEX; the columns
+                // that still have a particle are compacted into the other buffer, relabelled on the way (:331-337).  Occupancy
+                // of every old id (= its new count, :338) = sum over the live columns of (particles on the column) x (entries
+                // holding the id), in LDS (the term buffer and the hash / list tables are idle here) when the ids fit; otherwise
+                // the per-id scratch tables in global memory.
                 lint hist = sh.h1.key;                            // 9 * PMDI_HT_SIZE contiguous ints
                 const bool lm = oldmax + 1 <= 2 * a.terms_cap && oldmax + 1 <= 9 * PMDI_HT_SIZE;
                 lint lmap = (lint)sh.term;
+                lint mult = sh.slot_of;                           // particles per old column (slot_of is rebuilt at the top of every step)
+                lint cmap = sh.lead_of;                           // old column -> new column (INF again on exit)
+                const gint tmpc = pstar_raw;                      // (the ancestors were derived from it above: free)
                 PHR(3);   // (dataset loop top)
                 if (lm) for (int e = tid; e <= oldmax; e += T) { lmap[e] = 0; hist[e] = 0; }
                 for (int id = 1 + tid; id <= oldmax; id += T) s.counts[id] = 0;   // (:326)
+                for (int c = tid; c < ncol_old; c += T) mult[c] = 0;
                 __syncthreads();
-                {
-                    // the pass is a chain of L2 round trips (the ancestors' columns, then this slot's column): RB gathers of a
-                    // particle are in flight together and the next particle's ancestor is fetched a round ahead
-                    constexpr int RB = 10;
-                    int an_next = tid < P ? (int)ancp[tid] : 0;
-                    for (int pb = 0; pb < P; pb += T) {           // particle[:, partstar, k] (:322)
-                        const int p = pb + tid;
-                        const int an = an_next;
-                        if (p + T < P) an_next = ancp[p + T];
-                        if (p < P) {
-                            sidp[p] = (int)pidk[an];              // (:323)
-                            for (int nn = 0; nn < N; nn += RB) {
-                                int v[RB];
-#pragma unroll
-                                for (int u = 0; u < RB; ++u) v[u] = (nn + u < N) ? src[(nn + u) * P + an] : 0;
-#pragma unroll
-                                for (int u = 0; u < RB; ++u) if (nn + u < N) dst[(nn + u) * P + p] = v[u];
-                                if (lm) {
-#ifndef PMDI_RS_PLAIN_ATOMICS      // (A/B: one LDS add per entry instead -- measured 19 % slower per event at full load)
-#pragma unroll
-                                    for (int u = 0; u < RB; ++u) {
-                                        int cnt;
-                                        if (wave_group(v[u], nn + u < N, cnt)) atomicAdd(gen(&hist[v[u]]), cnt);
-                                    }
-#else
-#pragma unroll
-                                    for (int u = 0; u < RB; ++u) if (nn + u < N) __hip_atomic_fetch_add(gen(&hist[v[u]]), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-                                } else {
-#pragma unroll
-                                    for (int u = 0; u < RB; ++u) if (nn + u < N) s.ncop[v[u]] = 1;
-                                }
-                            }
-                        }
+                for (int pb = 0; pb < P; pb += T) {               // particle[:, partstar, k], particle_id[partstar, k] (:322-323)
+                    const int p = pb + tid;
+                    const bool valid = p < P;
+                    int nc = 0;
+                    if (valid) {
+                        const int an = ancp[p];
+                        sidp[p] = (int)pidk[an];
+                        nc = colk[an];
+                        tmpc[p] = nc;
                     }
+                    int cnt;
+                    if (wave_group(nc, valid, cnt)) atomicAdd(gen(&mult[nc]), cnt);
                 }
                 __syncthreads();
                 PHR(4);   // gather
-                for (int p = tid; p < P; p += T) pidk[p] = (int)sidp[p];
+                unsigned long long ccarry = 0;                    // new index of every column that kept a particle
+                for (int b = 0; b < ncol_old; b += T) {
+                    const int c = b + tid;
+                    const bool live = c < ncol_old && mult[c] != 0;
+                    unsigned long long tot;
+                    const unsigned long long ex = block_flag_scan<T>(live, false, false, tot, gen(sh.scan)) + ccarry;
+                    if (live) cmap[c] = (int)ex;
+                    ccarry += tot;
+                }
+                const int ncol_new = (int)ccarry;
+                for (int idx = tid; idx < ncol_old * N; idx += T) {
+                    const int m = mult[idx / N];
+                    if (m) {
+                        const int v = src[idx];
+                        if (lm) atomicAdd(gen(&hist[v]), m); else s.ncop[v] = 1;
+                    }
+                }
+                __syncthreads();
                 // sort(unique(particle)) ascending -> 1..U' (:329): scan of the live ids
                 unsigned long long carry = 0;
                 for (int b = 0; b < oldmax; b += T) {
@@ -1041,38 +1138,21 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 __syncthreads();
 #define PMDI_NEWID(id_) (lm ? lmap[(id_)] : (s.ncop[(id_)] ? s.firstc[(id_)] : 0))
                 const bool moves = newmax > 0 && PMDI_NEWID(newmax) != newmax;   // else ids 1..newmax stay put
-                // relabel (:331-337) -- and, on the global-table path, recount (:338)
-                if (moves || !lm) {
-                    for (int pb = 0; pb < P; pb += T) {
-                        const int p = pb + tid;
-                        const bool valid = p < P;
-                        constexpr int RB = 10;
-                        for (int nn0 = 0; nn0 < N; nn0 += RB) {           // RB labels per round: their reads overlap
-                            int v[RB];
-#pragma unroll
-                            for (int u = 0; u < RB; ++u) v[u] = (valid && nn0 + u < N) ? dst[(nn0 + u) * P + p] : 0;
-                            if (moves) {                                   // else every live id keeps its number
-#pragma unroll
-                                for (int u = 0; u < RB; ++u)
-                                    if (valid && nn0 + u < N) {
-                                        const int nv = PMDI_NEWID(v[u]);
-                                        if (nv != v[u]) dst[(nn0 + u) * P + p] = nv;
-                                        v[u] = nv;
-                                    }
-                            }
-                            if (!lm) {
-#pragma unroll
-                                for (int u = 0; u < RB; ++u) {
-                                    if (nn0 + u < N) {
-                                        int cnt;
-                                        if (wave_group(v[u], valid, cnt)) atomicAdd(gen(&s.counts[v[u]]), cnt);
-                                    }
-                                }
-                            }
-                        }
+                // the live columns, compacted and relabelled (:331-337) -- and, on the global-table path, the recount (:338)
+                for (int idx = tid; idx < ncol_old * N; idx += T) {
+                    const int c = idx / N;
+                    const int m = mult[c];
+                    if (m) {
+                        const int v = src[idx];
+                        const int nv = moves ? PMDI_NEWID(v) : v;
+                        dst[(size_t)cmap[c] * N + (idx - c * N)] = nv;
+                        if (!lm) atomicAdd(gen(&s.counts[nv]), m);
                     }
                 }
+                for (int p = tid; p < P; p += T) { colk[p] = cmap[tmpc[p]]; pidk[p] = (int)sidp[p]; }
                 __syncthreads();
+                for (int c = tid; c < ncol_old; c += T) cmap[c] = PMDI_INF_I;
+                if (tid == 0) { sh.kncol[k] = ncol_new; sh.wk[k * 8 + WK_COLS] += ncol_old; }
                 PHR(6);   // relabel + recount
                 if (lm) {
                     for (int e = tid; e <= oldmax && e < 9 * PMDI_HT_SIZE; e += T)       // tables back to empty (h2.b = INF)
@@ -1208,7 +1288,8 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
         if (a.pid_lds)   // debug export reads the class ids from global memory
             for (int k = 0; k < K; ++k) {
                 int *gp = (int *)(dsb[k].arena + (size_t)chain * dsb[k].stride + dsb[k].o_pid);
-                for (int p = tid; p < P; p += T) gp[p] = sh.pid[(size_t)k * P + p];
+                int *gc = (int *)(dsb[k].arena + (size_t)chain * dsb[k].stride + dsb[k].o_col);
+                for (int p = tid; p < P; p += T) { gp[p] = sh.pid[(size_t)k * P + p]; gc[p] = sh.col[(size_t)k * P + p]; }
             }
         if (tid < K) {
             a.kstate[((size_t)chain * PMDI_KMAX_I + kd0 + tid) * 2] = sh.kmaxid[tid];
@@ -1322,6 +1403,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             const int cur = sh.kcur[k];
             const gint part = s.part[cur];
             const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+            const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
             const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
             const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
             const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
@@ -1346,7 +1428,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             if (small) {
                 for (int w = tid; w < items; w += T) {
                     const int r = w / N, nn = w - r * N;
-                    const int id = part[nn * P + cl.lead(r)];
+                    const int id = part[(size_t)colk[cl.lead(r)] * N + nn];
                     sh.item_id[w] = id;
                     bool won;
                     const int slot = ht_insert(sh.h1, id, won, H);   // cannot fail: items <= ht_size/2
@@ -1454,7 +1536,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                         const int nn = lane + 64 * c;
                         if (nn < N) {
                             if (small) v2[c] = sh.lpl[sh.h1.a[ht_find(sh.h1, sh.item_id[r * N + nn])]];
-                            else v2[c] = s.lp[part[nn * P + cl.lead(r)]];
+                            else v2[c] = s.lp[part[(size_t)colk[cl.lead(r)] * N + nn]];
                             wv[nn] = v2[c];
                         }
                     }
@@ -1531,7 +1613,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     double v = 0.0;
                     if (valid) {
                         if (small) v = sh.lpl[sh.h1.a[ht_find(sh.h1, sh.item_id[r * N + nn])]];
-                        else v = s.lp[part[nn * P + cl.lead(r)]];
+                        else v = s.lp[part[(size_t)colk[cl.lead(r)] * N + nn]];
                     }
                     wv[lane] = v;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1623,7 +1705,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             bool ustep = false;
             if (fast) {
                 const int ns0 = ns0_cur;                                     // reference trajectory (:262), fetched a step ago
-                const int c0 = part[(size_t)ns0 * P];
+                const int c0 = part[(size_t)colk[0] * N + ns0];
                 int same = (ncls == 1) ? 1 : 0;
                 const bool one = ncls == 1;                                  // every particle reads CDF row 0
                 // split mode, one class with a one-hot CDF row: every particle gets the same increment, particle 0 the reference
@@ -1637,6 +1719,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     for (int u = 0; u < 4; ++u) {
                         const int p = pb0 + u * T + tid;
                         r_[u] = (!one && p < P) ? sh.slot_of[pidk[p]] : 0;
+                        c_[u] = (p < P) ? (int)colk[p] : 0;      // the particle's column, then its entry under the drawn label
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -1662,7 +1745,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                             for (; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
                         }
                         ns_[u] = ns;
-                        c_[u] = (p < P) ? part[ns * P + p] : 0;     // sstar_id (:264)
+                        c_[u] = (p < P) ? part[(size_t)c_[u] * N + ns] : 0;     // sstar_id (:264)
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -1697,9 +1780,10 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     nclone = needs ? 1 : 0;
                     new_ncls = 1;
                     if (maxid + nclone > cap) { failed = 1; break; }
-                    for (int p = tid; p < P; p += T) {
-                        pidk[p] = v;
-                        if (needs) part[(size_t)ns0 * P + p] = tgt;          // (:301-308)
+                    for (int p = tid; p < P; p += T) pidk[p] = v;
+                    if (needs) {                                             // (:301-308): every live column holds c0 under ns0
+                        const int ncol = sh.kncol[k];
+                        for (int c = tid; c < ncol; c += T) part[(size_t)c * N + ns0] = tgt;
                     }
                     if (tid == 0) {
                         if (freshk && a.q1 == 0) s.newid[key] = v;
@@ -1854,15 +1938,11 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 if (maxid + nclone > cap) { failed = 1; break; }
                 // -- E': apply (:301-308), sufficient statistics (:297,:300), table clean-up
                 PH(8); FRESH_LANE_IDS();
-                for (int pb = 0; pb < P; pb += T) {
-                    const int p = pb + tid;
-                    if (p < P) {
-                        const int slot = kvp[p];
-                        const int c = sh.h2.key[slot], tgt = sh.h2.a[slot];
-                        if (tgt != c) part[(int)sh.news[k * P + p] * P + p] = tgt;
-                        pidk[p] = sh.ktab_val[sidp[p]];
-                    }
-                }
+                columns_apply<T>(sh, s, part, colk, k, N, P, tid, (unsigned)(pos - (n1 - 1)) + 1u, [&](int p, int &c, int &tgt) {
+                    const int slot = kvp[p];
+                    c = sh.h2.key[slot]; tgt = sh.h2.a[slot];
+                });
+                for (int p = tid; p < P; p += T) pidk[p] = sh.ktab_val[sidp[p]];
                 stats_update_all<T, (T >= 512 && WPS <= 2) ? PMDI_VH_U : 4>(d, s, flk, gen(sh.xs), nd, D, tid, [&](int j, int &src, int &dst, int &nnew) {
                     src = sh.fl_p[j]; dst = sh.fl_tgt[j]; nnew = sh.fl_nnew[j];
                 });
