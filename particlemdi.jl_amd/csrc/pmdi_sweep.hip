@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     for (int c = tid; c <= P; c += T) { sh.lead_of[c] = PMDI_INF_I; sh.slot_of[c] = 0; }
     for (int e = tid; e < H; e += T) { sh.h1.key[e] = 0; sh.h1.a[e] = 0; sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
     for (int e = tid; e < a.item_cap; e += T) sh.ktab_minp[e] = PMDI_INF_I;
-    for (int e = tid; e < 2 * ((P >> 6) + 1); e += T) { sh.bm_fresh[e] = 0; sh.bm_clone[e] = 0; }
+    for (int e = tid; e < 2 * ((P >> 6) + 1); e += T) { sh.bm_fresh[e] = 0; sh.bm_clone[e] = 0; sh.bm_keep[e] = 0; sh.bm_reuse[e] = 0; }
 
     sweep_prefix<T>(ap);
     // ---- the sweep: src/pmdi.jl:209-342 ----
