@@ -60,7 +60,7 @@ def algorithmic_bytes(w, P, n, n1, work, stats):
     C = work.shape[0]
     tot = 0.0
     for k, (kind, D) in enumerate(zip(w["kinds"], w["D"])):
-        ev, up, cl, moved, mev = (work[:, k, j].astype(np.float64).sum() for j in range(5))
+        ev, up, cl, moved, mev, cols, splits = (work[:, k, j].astype(np.float64).sum() for j in range(7))
         if kind == "gaussian":                   # pool entry = (Sigma, beta) per feature (16 B) + n (4 B)
             b_eval, b_upd, b_clone_extra, b_x = 16 * D + 4, 2 * 16 * D + 8, 0, 8 * D
         elif kind == "categorical":              # one count per feature at the observed level; a clone copies L levels
@@ -68,11 +68,13 @@ def algorithmic_bytes(w, P, n, n1, work, stats):
             b_eval, b_upd, b_clone_extra, b_x = 4 * D + 4, 2 * 4 * D + 8, 2 * 4 * D * (L - 1), 4 * D
         else:                                    # NegBinom: Sigma per feature (8 B)
             b_eval, b_upd, b_clone_extra, b_x = 8 * D + 4, 2 * 8 * D + 8, 0, 4 * D
-        per_step = b_x + P * (4 + 1)                                   # obs row; label->cluster read + sstar byte per particle
-        prefix = (n1 - 1) * (b_x + 8) + N * P * 4 * 2                  # known-prefix rows + s_in/order; particle / new_id reset
+        per_step = b_x + P * (4 + 4 + 1)                               # obs row; per particle: column index, its label->cluster entry, sstar byte
+        prefix = (n1 - 1) * (b_x + 8) + N * P * (4 + 8) + P * 4        # known-prefix rows + s_in/order; new_id / split-scratch reset, column indices
         final = n * 4 + n_s * 1                                        # s_out write, sstar[p_star] reads
-        resample = stats[:, 1].astype(np.float64).sum() * (3 * N * P * 4 + P * 4)   # gather r+w, relabel read, class ids
-        tot += ev * b_eval + up * b_upd + cl * b_clone_extra + moved * (b_upd - 8) + mev * N * P * 4 \
+        # a resampling event: class ids and column indices of the P particles gathered (read + write each), the live columns of
+        # the particle -> cluster table read and written once (compacted + relabelled); a copy-on-write split copies a column
+        resample = stats[:, 1].astype(np.float64).sum() * (4 * P * 4) + cols * N * 4 * 2 + splits * N * 4 * 2
+        tot += ev * b_eval + up * b_upd + cl * b_clone_extra + moved * (b_upd - 8) \
             + resample + C * (n_s * per_step + prefix + final)
     return tot
 

@@ -41,6 +41,8 @@ EXPORTS = [
 def build(force=False, verbose=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU): one object per
     source under particlemdi.jl_amd/build/ (rebuilt when the source or a header is newer), then one link."""
+    if os.environ.get("PMDI_NO_BUILD") and os.path.exists(LIB_PATH):      # A/B runs of prebuilt variant libraries (PMDI_LIB_PATH)
+        return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("PMDI_EXTRA_HIPCC_FLAGS", "").split()
     bdir = os.path.join(_PKG, "build" if not os.environ.get("PMDI_LIB_PATH") else "build_ab")

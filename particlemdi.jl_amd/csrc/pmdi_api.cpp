@@ -463,7 +463,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             // headline workload even with the per-particle tables in global memory.  So: the largest set of per-particle
             // tables that still fits 80 KiB; if none does, one chain per CU with everything that fits 150 KiB in LDS.
             const char *tgt = getenv("PMDI_LDS_TARGET");
-            const size_t half = 80 * 1024;
+            const size_t half = 80 * 1024 - 256;      // half a CU's 160 KiB, less the kernel's static LDS (256 bytes of reduction scratch)
             bool fits_half = false;
             if (!tgt) {
                 for (int opt = 0; opt < 3 && !fits_half; ++opt) {
@@ -486,7 +486,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         {   // one chain per CU anyway: the 256-register build (no spills) instead of the register-capped one
             SweepArgs a;
             fill_sweep_common(h, a);
-            if (!getenv("PMDI_TWO_PER_CU") && pmdi_sweep_lds_bytes(a, h->T) > 80 * 1024) h->two_per_cu = 0;
+            if (!getenv("PMDI_TWO_PER_CU") && pmdi_sweep_lds_bytes(a, h->T) > 80 * 1024 - 256) h->two_per_cu = 0;
         }
         // automatic width: split the chains of a sweep into a heavy and a light launch
         h->split = cfg->block_threads == 0 && h->T > 256 && env_int("PMDI_SPLIT", 1) != 0;

@@ -58,6 +58,9 @@ def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, b
         wk, (up, mv) = g.sw.work_counters()[0], o.work()
         assert (wk[:, 1] == up).all() and (wk[:, 3] == mv).all() and wk[:, 2].sum() == ro["stats"]["n_clones"]
         assert (wk[:, 0] >= 1).all() and wk[:, 0].sum() <= ro["stats"]["n_operations"]      # evaluated <= the reference's count
+        # the particle -> cluster table is kept by distinct column: every resampling event meets 1..P live columns per dataset
+        nres = ro["stats"]["n_resamples"]
+        assert (wk[:, 5] >= nres).all() and (wk[:, 5] <= nres * P).all() and (wk[:, 6] >= 0).all()
         s = ro["s"]
     if check_state:
         eg, eo = g.sw.export_state(0), o.export()

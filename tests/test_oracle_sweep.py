@@ -127,3 +127,26 @@ def test_rejects_bad_inputs(O):
     Pi, Phi = random_hypers(rng, 4, 1)
     with pytest.raises(RuntimeError):
         o.sweep(1, rng.integers(1, 5, size=(20, 1)), np.arange(1, 21), 0, Pi, Phi)   # n1 >= 1 (Q8)
+
+
+def test_distinct_column_counter_matches_the_exported_table(O):
+    """The analysis hook behind scripts/column_stats.py (distinct columns of particle[:, :, k] per step) against a direct count
+    on the exported table after the last step of a sweep that ends without a resampling at its last observation."""
+    import ctypes as C
+    rng = np.random.default_rng(21)
+    data, kinds = make_mixed(rng, 120)
+    N, P, K, n, n1 = 6, 64, 3, 120, 30
+    o = O.Oracle(data, kinds, N, P, seed=3)
+    buf = np.zeros((n - n1 + 1, K), dtype=np.int64)
+    o.L.pmdi_oracle_debug_columns.argtypes = [C.c_void_p, C.c_void_p]
+    o.L.pmdi_oracle_debug_columns(o.h, buf.ctypes.data)
+    s = rng.integers(1, N + 1, size=(n, K))
+    for it in range(1, 4):
+        Pi, Phi = random_hypers(rng, N, K)
+        r = o.sweep(it, s, rng.permutation(n) + 1, n1, Pi, Phi, trace=True)
+        s = r["s"]
+        assert buf.min() >= 1 and buf.max() <= P
+        if r["trace"][-1, 1] == 0:          # no resampling after the last step: the exported table is the one that was counted
+            part = o.export()["particle"]
+            assert [len({tuple(col) for col in part[k]}) for k in range(K)] == list(buf[-1])
+    o.L.pmdi_oracle_debug_columns(o.h, None)
