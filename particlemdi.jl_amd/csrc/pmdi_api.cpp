@@ -129,11 +129,11 @@ struct pmdi_handle {
     int T = 0;
     long long cap = 0;
     int Dmax = 0, sumD = 0, npairs = 1;
-    int terms_cap = 0, pid_lds = 0, pp_lds = 0, two_per_cu = 0;
+    int terms_cap = 0, pid_lds = 0, pp_lds = 0, col_lds = 0, two_per_cu = 0;
     // light group (block_threads == 0 only): chains whose last sweep met few live clusters per step are
     // swept by 256-thread workgroups on a second stream, concurrently with the wide workgroups of the rest
     bool split = false;
-    int l_terms_cap = 0, l_pid_lds = 0, l_pp_lds = 0;
+    int l_terms_cap = 0, l_pid_lds = 0, l_pp_lds = 0, l_col_lds = 0;
     long long light_ids = 0;
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
@@ -209,7 +209,7 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.q1 = h->cfg.q1_mode; a.q2 = h->cfg.q2_mode;
     a.terms_cap = h->terms_cap;
     a.item_cap = h->cfg.N > 32 ? PMDI_ITEM_CAP_BIGN : PMDI_ITEM_CAP;
-    a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.two_per_cu = h->two_per_cu;
+    a.pid_lds = h->pid_lds; a.pp_lds = h->pp_lds; a.col_lds = h->col_lds; a.two_per_cu = h->two_per_cu;
     a.phase = h->phase_on ? (long long *)h->d_phase.p : nullptr;
     a.cost = (long long *)h->d_cost.p;
     a.work = (long long *)h->d_work.p;
@@ -271,7 +271,7 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
         }
         SweepArgs al = a;
         al.group_sel = 0; al.rank_lo = 0; al.rank_hi = C;
-        al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds;
+        al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds; al.col_lds = h->l_col_lds;
         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         e = pmdi_launch_sweep(al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (light group): %s", hipGetErrorString(e));
@@ -449,7 +449,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         // per workgroup width: LDS term buffer (at least P doubles for the resampling weights, the
         // per-wave CDF exchange areas, a few rows of 2*D+1) and which per-particle tables fit LDS
-        auto configure = [&](int T, int &terms_cap, int &pid_lds, int &pp_lds) -> int {
+        auto configure = [&](int T, int &terms_cap, int &pid_lds, int &pp_lds, int &col_lds) -> int {
             int tc = env_int("PMDI_TERMS_CAP", 1024);
             if (tc < P) tc = P;
             if (tc < (T / 64) * (N > 64 ? 256 : 128)) tc = (T / 64) * (N > 64 ? 256 : 128);   // per-wave exchange areas of the CDF stage
@@ -459,6 +459,8 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             SweepArgs a;
             fill_sweep_common(h, a);
             a.terms_cap = tc; a.pid_lds = 1; a.pp_lds = 1;
+            const int col_ok = 1;
+            a.col_lds = col_ok;
             // Two chains per CU (<= 80 KiB each) hide each other's dependent latencies: +40 % aggregate throughput on the
             // headline workload even with the per-particle tables in global memory.  So: the largest set of per-particle
             // tables that still fits 80 KiB; if none does, one chain per CU with everything that fits 150 KiB in LDS.
@@ -466,23 +468,26 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             const size_t half = 80 * 1024 - 256;      // half a CU's 160 KiB, less the kernel's static LDS (256 bytes of reduction scratch)
             bool fits_half = false;
             if (!tgt) {
-                for (int opt = 0; opt < 3 && !fits_half; ++opt) {
-                    a.pid_lds = opt < 1; a.pp_lds = opt < 2;
+                // (what a step reads of them, most often first: the column indices -- every step --, the step scratch, the class ids
+                // -- only in steps with more than one particle class)
+                for (int opt = 0; opt < 4 && !fits_half; ++opt) {
+                    a.pid_lds = opt < 1; a.pp_lds = opt < 3; a.col_lds = (opt < 2) ? col_ok : 0;
                     fits_half = pmdi_sweep_lds_bytes(a, T) <= half;
                 }
             }
             if (!fits_half) {
-                a.pid_lds = 1; a.pp_lds = 1;
+                a.pid_lds = 1; a.pp_lds = 1; a.col_lds = col_ok;
                 const size_t lds_target = tgt ? (size_t)atoi(tgt) : (size_t)150 * 1024;
                 if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pid_lds = 0;   // class ids of K*P particles do not fit: global memory
                 if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pp_lds = 0;    // nor does the per-particle step scratch
+                if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.col_lds = 0;   // nor do the column indices
             }
-            pid_lds = a.pid_lds; pp_lds = a.pp_lds;
+            pid_lds = a.pid_lds; pp_lds = a.pp_lds; col_lds = a.col_lds;
             if (pmdi_sweep_lds_bytes(a, T) > 160 * 1024)
                 return fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, T));
             return 0;
         };
-        if ((rc = configure(h->T, h->terms_cap, h->pid_lds, h->pp_lds))) return bail(rc);
+        if ((rc = configure(h->T, h->terms_cap, h->pid_lds, h->pp_lds, h->col_lds))) return bail(rc);
         {   // one chain per CU anyway: the 256-register build (no spills) instead of the register-capped one
             SweepArgs a;
             fill_sweep_common(h, a);
@@ -492,7 +497,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         h->split = cfg->block_threads == 0 && h->T > 256 && env_int("PMDI_SPLIT", 1) != 0;
         h->light_ids = env_int("PMDI_LIGHT_IDS", 40);
         if (h->split) {
-            if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds)) h->split = false;
+            if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
         }
         if (h->split) {
             // the slow chains bound the launch, so their workgroups must not queue behind the many

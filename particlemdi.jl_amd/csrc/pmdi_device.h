@@ -225,6 +225,26 @@ __device__ __forceinline__ bool wave_group(int key, bool valid, int &count)
     return leader;
 }
 
+// As wave_group, with at most `rounds` elections: lanes whose key has not come up by then speak for themselves (leader,
+// count 1).  For callers whose leader action is idempotent or additive (a flag, a counter, a compare-and-swap that one lane
+// wins): when a wave holds dozens of distinct keys the election loop costs more than the atomics it saves.
+__device__ __forceinline__ bool wave_group_capped(int key, bool valid, int &count, int rounds)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(valid);
+    bool leader = false;
+    count = 0;
+    for (int r = 0; r < rounds && active; ++r) {
+        const int l0 = __ffsll((long long)active) - 1;
+        const int k0 = __builtin_amdgcn_readlane(key, l0);
+        const unsigned long long m = __ballot(valid && key == k0);
+        if (lane == l0) { leader = true; count = __popcll(m); }
+        active &= ~m;
+    }
+    if ((active >> lane) & 1ull) { leader = true; count = 1; }
+    return leader;
+}
+
 // As wave_group, but every lane learns the lane id of its group's leader (lowest lane of the
 // group); `count` is set on leaders.
 __device__ __forceinline__ int wave_group_lead(int key, bool valid, int &count)

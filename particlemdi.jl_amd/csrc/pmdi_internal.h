@@ -76,6 +76,7 @@ struct SweepArgs {
     int terms_cap;          // doubles in the LDS term buffer
     int pid_lds;            // 1: particle class ids [K][P] live in LDS
     int pp_lds;             // 1: per-particle step scratch (sid, kv) lives in LDS
+    int col_lds;            // 1: the particles' column indices [K][P] live in LDS
     int two_per_cu;         // 1: register-capped build so that two chains co-reside on a CU
     int item_cap;           // (class, label) items a fast-path step may have: PMDI_ITEM_CAP, or PMDI_ITEM_CAP_BIGN when N > 32
     unsigned iter;

@@ -177,7 +177,7 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.term = take((size_t)a.terms_cap * 8);
     c.lw = take((size_t)a.P * 8);
     c.pid = take(a.pid_lds ? (size_t)KL * a.P * 4 : 0);
-    c.col = take(a.pid_lds ? (size_t)KL * a.P * 4 : 0);
+    c.col = take(a.col_lds ? (size_t)KL * a.P * 4 : 0);
     c.sid = take(a.pp_lds ? (size_t)a.P * 4 : 0);
     c.kv = take(a.pp_lds ? (size_t)a.P * 4 : 0);
     c.lead_of = take((size_t)(a.P + 1) * 4);
@@ -392,7 +392,7 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         const KS s = make_ks(d, chain);
         const int D = d.D;
         const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
-        const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
+        const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
         unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
         for (int idx = tid; idx <= cap; idx += T) { s.counts[idx] = 0; s.ncop[idx] = 0; s.firstc[idx] = PMDI_INF_I; }
         for (int idx = tid; idx < N * P; idx += T) { s.newid[idx] = 0; s.cgrp[idx] = 0; }
@@ -579,7 +579,7 @@ __device__ __forceinline__ void columns_apply(const Sh &sh, const KS &s, gint ta
         const bool w = valid && tgt != c;
         anyw |= w ? 1 : 0;
         int cnt;
-        if (wave_group(cl, valid && !w, cnt)) atomicOr(gen(&sh.bm_keep[cl >> 5]), 1u << (cl & 31));
+        if (wave_group_capped(cl, valid && !w, cnt, 8)) atomicOr(gen(&sh.bm_keep[cl >> 5]), 1u << (cl & 31));
     }
     if (!__syncthreads_or(anyw)) {                             // nothing was cloned: the table stands
         for (int e = tid; e < nbw; e += T) sh.bm_keep[e] = 0;
@@ -596,7 +596,7 @@ __device__ __forceinline__ void columns_apply(const Sh &sh, const KS &s, gint ta
         const bool w = valid && tgt != c;
         const int key = cl * N + ns;
         int cnt;
-        if (wave_group(key, w, cnt)) {
+        if (wave_group_capped(key, w, cnt, 8)) {
             unsigned long long *e = gen(s.cgrp + key);
             const unsigned long long old = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((old >> 32) != epoch && atomicCAS(e, old, etag) == old) {
@@ -716,7 +716,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     const int D = d.D;
     const gint part = s.part[sh.kcur[k]];
     const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
-    const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
+    const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
     const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
     const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
     const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
@@ -1068,7 +1068,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
                 const gcint src = s.part[cur];
                 const gint dst = s.part[cur ^ 1];
-                const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
+                const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
                 const int ncol_old = sh.kncol[k];
                 // The gather particle[:, partstar, k] (:322) by column: a particle takes its ancestor's column INDEX; the columns
                 // that still have a particle are compacted into the other buffer, relabelled on the way (:331-337).  Occupancy
@@ -1097,7 +1097,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                         tmpc[p] = nc;
                     }
                     int cnt;
-                    if (wave_group(nc, valid, cnt)) atomicAdd(gen(&mult[nc]), cnt);
+                    if (wave_group_capped(nc, valid, cnt, 8)) atomicAdd(gen(&mult[nc]), cnt);
                 }
                 __syncthreads();
                 PHR(4);   // gather
@@ -1288,8 +1288,12 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
         if (a.pid_lds)   // debug export reads the class ids from global memory
             for (int k = 0; k < K; ++k) {
                 int *gp = (int *)(dsb[k].arena + (size_t)chain * dsb[k].stride + dsb[k].o_pid);
+                for (int p = tid; p < P; p += T) gp[p] = sh.pid[(size_t)k * P + p];
+            }
+        if (a.col_lds)   // ... and the column indices
+            for (int k = 0; k < K; ++k) {
                 int *gc = (int *)(dsb[k].arena + (size_t)chain * dsb[k].stride + dsb[k].o_col);
-                for (int p = tid; p < P; p += T) { gp[p] = sh.pid[(size_t)k * P + p]; gc[p] = sh.col[(size_t)k * P + p]; }
+                for (int p = tid; p < P; p += T) gc[p] = (int)sh.col[(size_t)k * P + p];
             }
         if (tid < K) {
             a.kstate[((size_t)chain * PMDI_KMAX_I + kd0 + tid) * 2] = sh.kmaxid[tid];
@@ -1403,7 +1407,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             const int cur = sh.kcur[k];
             const gint part = s.part[cur];
             const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
-            const Dual<int> colk = dual(a.pid_lds != 0, sh.col + (size_t)k * P, s.col);
+            const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
             const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
             const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
             const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
