@@ -52,7 +52,7 @@ DESCR = {
 DEFAULTS = {"HL": (1024, 20), "cfg2": (2048, 30), "cfg3": (1024, 12), "cfg4": (256, 6), "cfg5": (256, 3)}
 
 
-def algorithmic_bytes(w, P, n, n1, work, stats):
+def algorithmic_bytes(w, P, n, n1, work, stats, layout="column"):
     """De-duplication-aware algorithmic HBM bytes of one sweep of every chain, from the kernel's own work counters
     (pmdi_work_counters; DESIGN.md section 6 has the derivation).  work: (C, K, 8); stats: (C, 8)."""
     N, K = w["N"], w["K"]
@@ -74,6 +74,10 @@ def algorithmic_bytes(w, P, n, n1, work, stats):
         # a resampling event: class ids and column indices of the P particles gathered (read + write each), the live columns of
         # the particle -> cluster table read and written once (compacted + relabelled); a copy-on-write split copies a column
         resample = stats[:, 1].astype(np.float64).sum() * (4 * P * 4) + cols * N * 4 * 2 + splits * N * 4 * 2
+        if layout == "particle":                 # the N x P table per particle of the earlier builds: same work, more bytes
+            per_step = b_x + P * (4 + 1)
+            prefix = (n1 - 1) * (b_x + 8) + N * P * 4 * 2
+            resample = stats[:, 1].astype(np.float64).sum() * (3 * N * P * 4 + P * 4) + mev * N * P * 4
         tot += ev * b_eval + up * b_upd + cl * b_clone_extra + moved * (b_upd - 8) \
             + resample + C * (n_s * per_step + prefix + final)
     return tot
@@ -287,6 +291,7 @@ def main():
         clock_hz = float(sw.clock_hz)
         chain_s = costs / clock_hz
         alg = algorithmic_bytes(w, P, n, n1, work, stats)                       # bytes of the last timed sweep, all chains
+        alg_pp = algorithmic_bytes(w, P, n, n1, work, stats, layout="particle")   # same work on the per-particle N x P table of the earlier builds
         dense = float(workloads.algorithmic_bytes_per_obs_particle(w["kinds"], w["D"], N)) * n_s * P * C
         achieved = alg / (kernel_ms * 1e-3)
         traffic = None
@@ -327,9 +332,14 @@ def main():
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / alg) if traffic else None,
                          "algorithmic_bytes_per_sweep": alg, "dense_model_ratio": dense / alg,
+                         "per_particle_table_model": {"algorithmic_bytes_per_sweep": alg_pp, "frac": alg_pp / (kernel_ms * 1e-3) / HBM_PEAK,
+                                                      "note": "the same sweep priced with the byte model of the builds that kept particle[:, :, k] "
+                                                              "as an N x P table per particle (rounds 1-2 before the column table): what frac "
+                                                              "compares with across rounds; the column table needs ~4x fewer bytes for the same work"},
                          "note": "achieved = de-duplication-aware algorithmic bytes of one sweep (built from the kernel's work counters: "
                                  "clusters evaluated / updated / cloned / moved, resampling events, per-step and per-sweep streams; "
-                                 "DESIGN.md section 6) / sweep time. dense_model_ratio = SURVEY 8d's dense-model bytes / these: the work "
+                                 "DESIGN.md section 6) / sweep time. traffic = PMC-measured HBM bytes per sweep of this operating point (profiles/hbm_traffic.json); at HL "
+                                 "three quarters of it are register-spill write-backs (WRITE_SIZE), not algorithmic bytes: profiles/README.md. dense_model_ratio = SURVEY 8d's dense-model bytes / these: the work "
                                  "the reference's de-duplication (kept here) avoids. A sweep is bound by dependent latency, not by HBM."},
         }
     if comm is not None:

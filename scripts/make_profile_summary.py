@@ -17,6 +17,9 @@ import numpy as np
 
 tag, key, steps, d_trace = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 passes = dict(a.split("=", 1) for a in sys.argv[5:])
+# bench.py's latency-form leg (K > 1) launches the one-dataset-per-workgroup builds `<T, WPS, true>` after the timed region:
+# PMDI_KERNEL_FILTER="false>" keeps the throughput-form launches only
+FLT = os.environ.get("PMDI_KERNEL_FILTER", "")
 out = os.path.join("profiles", tag); os.makedirs(out, exist_ok=True)
 
 
@@ -29,7 +32,7 @@ def f1(d, *pats):
 
 
 def sweep_sets(d):
-    rows = [r for r in csv.DictReader(open(f1(d, "*kernel_trace.csv"))) if "pmdi_sweep_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f1(d, "*kernel_trace.csv"))) if "pmdi_sweep_kernel" in r["Kernel_Name"] and FLT in r["Kernel_Name"]]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     sets, cur = [], []
     for r in rows:      # a new set starts when a launch begins after the running set has ended and > 2 ms after it began
@@ -58,7 +61,7 @@ for s in sets[-steps:]:
 def counters(d):
     """{counter: mean over the timed sets of the sum over the set's dispatches}; under counter collection the launches of a
     set run one after the other, so sets are rebuilt from that pass's own kernel trace by dispatch order."""
-    rs = [r for r in csv.DictReader(open(f1(d, "*counter_collection.csv", "*counter_collection_trace.csv"))) if "pmdi_sweep_kernel" in r["Kernel_Name"]]
+    rs = [r for r in csv.DictReader(open(f1(d, "*counter_collection.csv", "*counter_collection_trace.csv"))) if "pmdi_sweep_kernel" in r["Kernel_Name"] and FLT in r["Kernel_Name"]]
     per = {}
     for r in rs:
         per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
