@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "particlemdi.jl_amd", "csrc", "pmdi_sweep.hip")
 BUDGET = {            # (T, WPS, K1) -> max VGPR spill slots as `-Rpass-analysis=kernel-resource-usage` reports them for the kernel (the
     # figure covers the out-of-line device functions it calls: dropping two stores from the resampling function alone moved the
-    # 256-thread build from 63 to 27).  Measured 218 / 44 / 26 with the particle -> cluster table kept by column (round 2, late:
+    # 256-thread build from 63 to 27).  Measured 203 / 46 / 29 with the particle -> cluster table kept by column (round 2, late:
     # the copy-on-write split is inlined twice into the step loop); 166 / 17 / 15 before that; 124 / 8 / 9 in round 1.
     "ILi512ELi4ELb1": 225,
     "ILi512ELi2ELb1": 48,
