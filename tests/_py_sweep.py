@@ -163,10 +163,11 @@ def draw_partstar(logweight, particles, u01, uslot):    # src/misc.jl:27-47
     return [1] + partstar
 
 
-def sweep(data, kinds, N, P, s, order_obs, n1, Pi, Phi, flags, uniform, it, lw_init, q1_mode=0, q2_mode=0):
+def sweep(data, kinds, N, P, s, order_obs, n1, Pi, Phi, flags, uniform, it, lw_init, q1_mode=0, q2_mode=0, shadow=None):
     """One iteration's sweep (src/pmdi.jl:165-171, 188-350, 373).  1-based like the reference: s (n+1, K+1) labels,
     order_obs list of 1-based rows, Pi (N+1, K+1).  uniform(it, pos, k, p, site) -> (0,1) with pos / k / p 0-based
-    (the oracle's key layout).  Returns (s_new (n, K) 1-based labels, p_star, logweight list, counters)."""
+    (the oracle's key layout).  shadow: an optional tests/_py_columns.ColumnShadow that is told of every change of
+    particle[:, :, k] and checked against it (it never feeds back into the sweep).  Returns (s_new (n, K) 1-based labels, p_star, logweight list, counters)."""
     K, n = len(data), data[0].shape[0]
     new, logp, add = zip(*[TYPES[k] for k in kinds])
     logweight = [lw_init] * P
@@ -200,6 +201,8 @@ def sweep(data, kinds, N, P, s, order_obs, n1, Pi, Phi, flags, uniform, it, lw_i
             for p in range(1, P + 1):
                 sstar[k][p][i] = s[i][k]
             add[k - 1](clusters[k][idc], data[k - 1][i - 1], flags[k - 1])
+        if shadow:
+            shadow.init(k, [0] + [particle[k][nn][1] for nn in range(1, N + 1)])
     # :209-342
     for pos in range(n1 - 1, n):
         i = order_obs[pos]
@@ -256,6 +259,7 @@ def sweep(data, kinds, N, P, s, order_obs, n1, Pi, Phi, flags, uniform, it, lw_i
                 else:
                     particle_id[k][p] = new_id[k][new_s][idc]
             max_k = max(max(row[1:]) for row in particle[k][1:])
+            tgt_of = {}
             for pc in sstar_id[k][1:]:
                 if pc not in cluster_update:
                     cluster_update[pc] = True
@@ -270,11 +274,15 @@ def sweep(data, kinds, N, P, s, order_obs, n1, Pi, Phi, flags, uniform, it, lw_i
                         max_k += 1
                         n_clones += 1
                     add[k - 1](clusters[k][idc], obs, flags[k - 1])
+                    tgt_of[pc] = idc
                     if idc != pc:
                         for part in range(1, P + 1):
                             s_id = sstar[k][part][i]
                             if particle[k][s_id][part] == pc:
                                 particle[k][s_id][part] = idc
+            if shadow:
+                shadow.step(k, [0] + [sstar[k][p][i] for p in range(1, P + 1)], list(sstar_id[k]), tgt_of)
+                shadow.check(k, particle[k])
         if K > 1:                                            # Phi_upweight! (src/misc.jl:50-59)
             pr = 0
             for k1 in range(1, K):
@@ -294,6 +302,7 @@ def sweep(data, kinds, N, P, s, order_obs, n1, Pi, Phi, flags, uniform, it, lw_i
                     sstar[k] = [None] + [list(sstar[k][a]) for a in partstar]
                 counts[k] = [0] * (N * P + 2)
                 ids = sorted({particle[k][nn][p] for nn in range(1, N + 1) for p in range(1, P + 1)})
+                occ = shadow.resample(k, partstar, {idc: inew for inew, idc in enumerate(ids, start=1)}) if shadow else None
                 for inew, idc in enumerate(ids, start=1):
                     if idc != inew:
                         for nn in range(1, N + 1):
@@ -302,6 +311,9 @@ def sweep(data, kinds, N, P, s, order_obs, n1, Pi, Phi, flags, uniform, it, lw_i
                                     particle[k][nn][p] = inew
                         clusters[k][inew] = copy.deepcopy(clusters[k][idc])
                     counts[k][inew] = sum(1 for nn in range(1, N + 1) for p in range(1, P + 1) if particle[k][nn][p] == inew)
+                if shadow:
+                    shadow.check(k, particle[k])
+                    assert occ == {inew: counts[k][inew] for inew in range(1, len(ids) + 1)}
     # :345-350, StatsBase sample(::Weights)
     mx = max(logweight)
     w = [math.exp(l - mx) for l in logweight]

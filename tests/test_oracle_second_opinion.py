@@ -97,3 +97,30 @@ def test_random_small_configurations(O, seed):
     flags = [(rng.random(d.shape[1]) < 0.8).astype(np.uint8) for d in data] if seed % 2 else None
     _run_both(O, data, kinds, N=N, P=P, seed=seed, iters=2, n1=max(2, int(rng.integers(2, n // 2))), q1=seed % 2, q2=(seed // 2) % 2,
               flags=flags, rng=rng)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_column_table_shadows_the_literal_table(O, seed):
+    """The device keeps particle[:, :, k] by distinct column (DESIGN.md 4.3).  tests/_py_columns.py restates that scheme;
+    here it shadows the literal N x P table of the Python sweep through every step and resampling event -- equal tables,
+    equal occupancies, no empty column, never more than P -- with the arbitrary "which group keeps the column" choice shuffled."""
+    import _py_columns as PC
+    rng = np.random.default_rng(700 + seed)
+    K, N, P, n = int(rng.integers(1, 4)), int(rng.integers(2, 7)), int(rng.integers(2, 33)), int(rng.integers(20, 60))
+    z = rng.integers(0, 3, n)
+    data = [rng.normal(size=(n, 3)) + 2.0 * z[:, None] for _ in range(K)]
+    kinds = ["gaussian"] * K
+    uni = lambda it, pos, k, p, site: O.uniform(seed, it, pos, k, p, site)
+    flags = [np.ones(3, dtype=bool)] * K
+    s = rng.integers(1, N + 1, size=(n, K))
+    seen_cols = 0
+    for it in range(1, 3):
+        Pi, Phi = random_hypers(rng, N, K)
+        order = rng.permutation(n) + 1
+        s1 = np.zeros((n + 1, K + 1), dtype=np.int64); s1[1:, 1:] = s
+        Pi1 = np.zeros((N + 1, K + 1)); Pi1[1:, 1:] = Pi
+        sh = PC.ColumnShadow(K, N, P, order_seed=seed)
+        s, _, _, cnt, _ = PS.sweep(data, kinds, N, P, s1.tolist(), order.tolist(), max(2, n // 4), Pi1.tolist(), list(np.atleast_1d(Phi)),
+                                    flags, uni, it, 0.0 if it == 1 else 1.0, q1_mode=seed % 2, shadow=sh)
+        seen_cols = max(seen_cols, sh.max_cols)
+    assert 1 <= seen_cols <= P
