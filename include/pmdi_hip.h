@@ -164,7 +164,8 @@ int pmdi_feature_select(pmdi_handle *h, int64_t iter, const int64_t *s_traj,
  * by __pmdi() (src/__pmdi.jl:342) so that the invariants of
  * test/runtests.jl:147-162 can be run on the device path.  Per chain:
  *   particle  N x P x K Int64 (cluster ids)      counts   pool_cap x K Int64
- *   cluster_n pool_cap x K Int64 (cl.n per id)   max_id   K Int64 */
+ *   cluster_n pool_cap x K Int64 (cl.n per id)   max_id   K Int64
+ * (particle is expanded from the device's column table: distinct columns + a column index per particle.) */
 int pmdi_export_state(pmdi_handle *h, int32_t chain, int64_t *particle, int64_t *counts,
                       int64_t *cluster_n, int64_t *max_id);
 
@@ -305,7 +306,9 @@ int pmdi_chain_costs(pmdi_handle *h, int64_t *out);
  * was evaluated (the kernel evaluates only clusters a particle-class leader can reach, src/pmdi.jl:232; the
  * reference's count of :218-220 is n_operations), [1] distinct clusters updated (cluster_add!, :300), [2] of which
  * cloned (:297), [3] cluster ids moved by the renumbering of resampling events (:336), [4] resampling events that
- * moved any.  bench.py builds its de-duplication-aware algorithmic byte count from these. */
+ * moved any, [5] distinct columns of particle[:, :, k] met by the resampling events, summed (the device stores the table by
+ * distinct column: a settled chain holds about ten for 1 024 particles), [6] columns created by copy-on-write splits (:301-308).
+ * bench.py builds its de-duplication-aware algorithmic byte count from these. */
 int pmdi_work_counters(pmdi_handle *h, int64_t *out);
 
 int pmdi_sum_D(const pmdi_handle *h);
