@@ -100,3 +100,26 @@ def test_csv_writer_bytes(pkg, tmp_path):
     w.flags([1, 0, 1])
     w.close()
     assert pf.read_bytes() == b"a_d1,a_d2,b_d1\ntrue,false,true\n"
+
+
+def test_bench_byte_models():
+    """bench.py's algorithmic byte count: the column-table model against a hand count, and against the per-particle-table model
+    of the earlier builds (same counters, more bytes)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pmdi_bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    w = {"N": 4, "K": 1, "kinds": ["gaussian"], "D": [3], "data": [None]}
+    C, n, n1, P = 2, 10, 3, 8
+    work = np.zeros((C, 1, 8), dtype=np.int64)
+    work[:, 0, :7] = [5, 4, 1, 2, 1, 6, 3]          # evaluated, updated, cloned, moved, move events, columns at resampling, splits
+    stats = np.zeros((C, 8), dtype=np.int64); stats[:, 1] = 5
+    n_s, N, D = n - n1 + 1, 4, 3
+    per_chain = (5 * (16 * D + 4) + 4 * (32 * D + 8) + 2 * 32 * D                       # pool: evaluated, updated, moved
+                 + 5 * 16 * P + 6 * N * 8 + 3 * N * 8                                     # resampling: ids + columns gathered, live columns, splits
+                 + n_s * (8 * D + 9 * P) + (n1 - 1) * (8 * D + 8) + N * P * 12 + P * 4     # per step, prefix
+                 + n * 4 + n_s)                                                            # output
+    assert b.algorithmic_bytes(w, P, n, n1, work, stats) == C * per_chain
+    assert b.algorithmic_bytes(w, P, n, n1, work, stats, layout="particle") > C * per_chain
