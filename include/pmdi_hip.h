@@ -268,6 +268,15 @@ int pmdi_csv_write_gibbs(pmdi_csv *w, pmdi_gibbs *g, int32_t chain, double ll);
 int pmdi_csv_open_features(const char *path, int32_t K, const int32_t *D, const char *const *data_names, pmdi_csv **out);
 int pmdi_csv_write_flags(pmdi_csv *w, const uint8_t *flags);
 int pmdi_csv_close(pmdi_csv *w);
+/* Reader side of the output file: what generate_psm, src/output_analysis/consensus_map.jl:32-47, takes
+ * from it.  K = header names containing "MassParameter" (:34-36); the data rows after `burnin`, every `thin`-th of them
+ * (:33,:38); the allocation columns from K + binomial(K, 2) + (K == 1) + 2 on (:38); n_obs = their number / K, an error if that
+ * is not an integer (:40-41); names = the K distinct prefixes before the first '_' of those columns (:47), '\n'-separated.
+ * labels (may be NULL: sizes only): bytes [row][k][i], the layout pmdi_psm_counts_device takes, labels_cap bytes available.
+ * Host-only. */
+int pmdi_csv_read_allocations(const char *path, int64_t burnin, int64_t thin, int32_t *K_out, int64_t *n_obs_out,
+                              int64_t *n_iter_out, uint8_t *labels, int64_t labels_cap, char *names, int32_t names_cap);
+
 /* Base.show(::Float64) of one number into out (NUL-terminated); returns its length or a negative error */
 int pmdi_format_float64(double x, char *out, int32_t cap);
 

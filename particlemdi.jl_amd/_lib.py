@@ -32,7 +32,7 @@ EXPORTS = [
     "pmdi_gibbs_create", "pmdi_gibbs_destroy", "pmdi_gibbs_iterate", "pmdi_gibbs_step", "pmdi_gibbs_iterations",
     "pmdi_gibbs_get", "pmdi_gibbs_set", "pmdi_gibbs_results", "pmdi_gibbs_device_view", "pmdi_gibbs_pack_samples",
     "pmdi_csv_open", "pmdi_csv_write_row", "pmdi_csv_write_gibbs", "pmdi_csv_open_features", "pmdi_csv_write_flags",
-    "pmdi_csv_close", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz", "pmdi_is_split",
+    "pmdi_csv_close", "pmdi_csv_read_allocations", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz", "pmdi_is_split",
     "pmdi_comm_unique_id", "pmdi_comm_init_rank", "pmdi_comm_init_all", "pmdi_comm_destroy", "pmdi_comm_rank", "pmdi_comm_size",
     "pmdi_allgather_samples",
 ]
@@ -217,6 +217,8 @@ def lib():
     L.pmdi_csv_write_flags.restype = C.c_int
     L.pmdi_csv_write_flags.argtypes = [vp, vp]
     L.pmdi_csv_close.argtypes = [vp]
+    L.pmdi_csv_read_allocations.restype = C.c_int
+    L.pmdi_csv_read_allocations.argtypes = [C.c_char_p, i64, i64, vp, vp, vp, vp, i64, C.c_char_p, i32]
     L.pmdi_format_float64.restype = C.c_int
     L.pmdi_format_float64.argtypes = [dbl, C.c_char_p, i32]
     _lib = L
@@ -407,6 +409,18 @@ class CsvWriter:
             self.close()
         except Exception:
             pass
+
+
+def read_allocations(path, burnin=0, thin=1):
+    """The allocation samples of a pmdi() output file as generate_psm reads them (consensus_map.jl:32-47), through the native
+    reader: (samples uint8 (rows kept, K, n_obs), dataset names)."""
+    K, n, S = C.c_int32(0), C.c_int64(0), C.c_int64(0)
+    names = C.create_string_buffer(1 << 16)
+    pth = str(path).encode()
+    _check(lib().pmdi_csv_read_allocations(pth, int(burnin), int(thin), C.byref(K), C.byref(n), C.byref(S), None, 0, names, len(names)))
+    out = np.zeros((S.value, K.value, n.value), dtype=np.uint8)
+    _check(lib().pmdi_csv_read_allocations(pth, int(burnin), int(thin), C.byref(K), C.byref(n), C.byref(S), _ptr(out), out.size, None, 0))
+    return out, names.value.decode().split("\n")
 
 
 def format_float64(x):

@@ -171,6 +171,104 @@ int pmdi_csv_close(pmdi_csv *w)
     return PMDI_OK;
 }
 
+// Reader side: what generate_psm (src/output_analysis/consensus_map.jl:32-46) takes from an output file --
+// K from the header (names containing "MassParameter", :34-36), the data rows after `burnin`, every `thin`-th of them (:33,:38),
+// the allocation columns from K + binomial(K, 2) + (K == 1) + 2 on (:38), n_obs = columns / K (:40-42), the dataset names =
+// unique prefixes before the first '_' of those columns (:47).  Labels come back as bytes [row][k][i] (the layout
+// pmdi_psm_counts_device takes); a field that is not an integer in 0..255 is an error (the reference would compare any Float64).
+int pmdi_csv_read_allocations(const char *path, int64_t burnin, int64_t thin, int32_t *K_out, int64_t *n_obs_out, int64_t *n_iter_out,
+                              uint8_t *labels, int64_t labels_cap, char *names, int32_t names_cap)
+{
+    if (!path || burnin < 0 || thin < 1) return pmdi_set_error(PMDI_E_ARG, "pmdi_csv_read_allocations: bad argument");
+    FILE *f = fopen(path, "r");
+    if (!f) return pmdi_set_error(PMDI_E_ARG, "cannot open %s", path);
+    std::string line;
+    auto getline_ = [&](std::string &out) -> bool {
+        out.clear();
+        int ch;
+        bool any = false;
+        while ((ch = fgetc(f)) != EOF) {
+            any = true;
+            if (ch == '\n') break;
+            if (ch != '\r') out += (char)ch;
+        }
+        return any;
+    };
+    if (!getline_(line)) { fclose(f); return pmdi_set_error(PMDI_E_DATA, "%s: empty file", path); }
+    std::vector<std::string> hdr;
+    {
+        size_t a0 = 0;
+        for (;;) {
+            const size_t c = line.find(',', a0);
+            hdr.push_back(line.substr(a0, c == std::string::npos ? std::string::npos : c - a0));
+            if (c == std::string::npos) break;
+            a0 = c + 1;
+        }
+    }
+    int K = 0;
+    for (const std::string &h : hdr) if (h.find("MassParameter") != std::string::npos) ++K;
+    if (K < 1) { fclose(f); return pmdi_set_error(PMDI_E_DATA, "%s: no MassParameter column in the header", path); }
+    const long long first = (long long)K + (long long)K * (K - 1) / 2 + (K == 1 ? 1 : 0) + 1;     // 0-based index of the first allocation column
+    const long long ncol = (long long)hdr.size();
+    if (ncol <= first || (ncol - first) % K != 0) {
+        fclose(f);
+        return pmdi_set_error(PMDI_E_DATA, "Error: Datasets have different number of observations");   // consensus_map.jl:41
+    }
+    const long long n_obs = (ncol - first) / K;
+    // names: unique prefixes, in order of first appearance
+    std::vector<std::string> uniq;
+    for (long long c = first; c < ncol; ++c) {
+        const std::string pre = hdr[(size_t)c].substr(0, hdr[(size_t)c].find('_'));
+        bool seen = false;
+        for (const std::string &u : uniq) if (u == pre) { seen = true; break; }
+        if (!seen) uniq.push_back(pre);
+    }
+    if ((int)uniq.size() != K) {
+        fclose(f);
+        return pmdi_set_error(PMDI_E_DATA, "%s: %d distinct dataset names for K = %d datasets", path, (int)uniq.size(), K);
+    }
+    if (names) {
+        std::string all;
+        for (int k = 0; k < K; ++k) { if (k) all += '\n'; all += uniq[(size_t)k]; }
+        if ((int)all.size() + 1 > names_cap) { fclose(f); return pmdi_set_error(PMDI_E_ARG, "names buffer too small"); }
+        memcpy(names, all.c_str(), all.size() + 1);
+    }
+    long long row = 0, kept = 0;
+    while (getline_(line)) {
+        if (line.empty()) continue;                    // readdlm skips blank lines
+        const long long r = row++;
+        if (r < burnin || (r - burnin) % thin != 0) continue;
+        if (labels) {
+            if ((kept + 1) * n_obs * K > labels_cap) { fclose(f); return pmdi_set_error(PMDI_E_ARG, "labels buffer too small"); }
+            const char *p = line.c_str();
+            long long c = 0;
+            for (; *p; ++c) {
+                const char *e = p;
+                while (*e && *e != ',') ++e;
+                if (c >= first) {
+                    if (c >= ncol) break;
+                    double v = 0.0;
+                    const auto res = std::from_chars(p, e, v);
+                    if (res.ec != std::errc() || res.ptr != e || v < 0.0 || v > 255.0 || v != std::floor(v)) {
+                        fclose(f);
+                        return pmdi_set_error(PMDI_E_DATA, "%s: data row %lld, column %lld: not a label in 0..255", path, r + 1, c + 1);
+                    }
+                    const long long a1 = c - first;                      // column-major s[1:(n_obs * K)]: dataset = a1 / n_obs
+                    labels[(kept * K + a1 / n_obs) * n_obs + a1 % n_obs] = (uint8_t)v;
+                }
+                p = *e ? e + 1 : e;
+            }
+            if (c < ncol) { fclose(f); return pmdi_set_error(PMDI_E_DATA, "%s: data row %lld has %lld fields, the header %lld", path, r + 1, c, ncol); }
+        }
+        ++kept;
+    }
+    fclose(f);
+    if (K_out) *K_out = K;
+    if (n_obs_out) *n_obs_out = n_obs;
+    if (n_iter_out) *n_iter_out = kept;
+    return PMDI_OK;
+}
+
 int pmdi_format_float64(double x, char *out, int32_t cap)
 {
     std::string b;

@@ -287,6 +287,21 @@ function pmdi_device(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float
     return
 end
 
+# ---- generate_psm's reading of an output file (src/output_analysis/consensus_map.jl:32-47), natively ----------
+# returns (samples::Array{UInt8,3} of size (n_obs, K, rows kept) -- i.e. [row][k][i] in C order --, names)
+function read_allocations(outputFile::String, burnin::Int64 = 0, thin::Int64 = 1)
+    K = Ref{Int32}(0); n_obs = Ref{Int64}(0); n_iter = Ref{Int64}(0)
+    names = Vector{UInt8}(undef, 1 << 16)
+    check(ccall((:pmdi_csv_read_allocations, LIB), Cint,
+                (Cstring, Int64, Int64, Ref{Int32}, Ref{Int64}, Ref{Int64}, Ptr{UInt8}, Int64, Ptr{UInt8}, Int32),
+                outputFile, burnin, thin, K, n_obs, n_iter, C_NULL, 0, names, length(names)))
+    samples = Array{UInt8, 3}(undef, n_obs[], K[], n_iter[])
+    check(ccall((:pmdi_csv_read_allocations, LIB), Cint,
+                (Cstring, Int64, Int64, Ref{Int32}, Ref{Int64}, Ref{Int64}, Ptr{UInt8}, Int64, Ptr{UInt8}, Int32),
+                outputFile, burnin, thin, K, n_obs, n_iter, samples, length(samples), C_NULL, 0))
+    return samples, split(unsafe_string(pointer(names)), '\n')
+end
+
 # ---- the cluster plugin protocol on the device (unit-level entry points) ----------------------
 # calc_logprob / cluster_add! / calc_logmarginal for a batch of stand-alone clusters of dataset k;
 # see pmdi_clusters_new, pmdi_cluster_add, pmdi_calc_logprob, pmdi_calc_logmarginal in the header.

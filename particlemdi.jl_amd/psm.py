@@ -78,3 +78,32 @@ def psm_rows(samples, row_lo, row_hi, n_labels=0, host=False):
             out[K] += torch.div(out[k], K_t)
         out[K] = out[K] * (1.0 - eye) + eye       # diagind .= 1.0
     return out.numpy() if is_np else out
+
+
+class PosteriorSimilarityMatrix:
+    """`Posterior_similarity_matrix` of consensus_map.jl:6-11: `psm` = K (+1 "Overall" if K > 1) n x n Float64 matrices,
+    `names` = the dataset names (+ "Overall")."""
+
+    def __init__(self, psm, names):
+        self.psm, self.names = psm, names
+
+
+def generate_psm(outputFile, burnin=0, thin=1, host=False, device=None):
+    """generate_psm(outputFile, burnin, thin) of src/output_analysis/consensus_map.jl:31-65 on a file written by pmdi():
+    the native reader (pmdi_csv_read_allocations) takes the allocation samples, the co-clustering counts come from the HIP
+    kernels (pmdi_psm_counts_device) and the division / identity / "Overall" average follow :50-63.  host=True runs the plain
+    host mirror instead (tests, machines without an MI355X); there is no silent fallback."""
+    import torch
+    from ._lib import read_allocations
+    samples, names = read_allocations(outputFile, burnin, thin)
+    S, K, n = samples.shape
+    if S < 1:
+        raise ValueError("generate_psm: no rows left after burn-in and thinning")
+    if host:
+        rows = psm_rows(samples, 0, n, host=True)
+    else:
+        if not torch.cuda.is_available():
+            raise RuntimeError("generate_psm: no MI355X visible; pass host=True for the host mirror")
+        dev = torch.device("cuda", 0 if device is None else int(device))
+        rows = psm_rows(torch.from_numpy(samples).to(dev), 0, n, n_labels=int(samples.max()) + 1).cpu().numpy()
+    return PosteriorSimilarityMatrix([rows[k] for k in range(rows.shape[0])], list(names) + (["Overall"] if K > 1 else []))

@@ -138,6 +138,24 @@ def test_psm_counts_on_device(pkg, O, S, K, n, lo, hi, nlab):
     assert (rows_dev == rows_host).all()
 
 
+@pytest.mark.gpu
+def test_generate_psm_from_an_output_file_on_the_device(pkg, tmp_path):
+    """generate_psm(outputFile, burnin, thin) (consensus_map.jl:31-65) end to end -- native reader, HIP counts,
+    division and "Overall" -- equals the host mirror (which tests/test_host.py pins to the reference's loops)."""
+    from particlemdi_jl_amd.psm import generate_psm
+    rng = np.random.default_rng(12)
+    K, n, iters, N = 3, 70, 40, 6
+    path = tmp_path / "out.csv"
+    w = pkg.CsvWriter(path, K, n, data_names=["a", "b", "c"])
+    for _ in range(iters):
+        w.row(rng.gamma(2.0, 1.0, K), rng.gamma(1.0, 1.0, 3), -1.0, rng.integers(1, N + 1, size=(n, K)))
+    w.close()
+    dev, host = generate_psm(str(path), 4, 3), generate_psm(str(path), 4, 3, host=True)
+    assert dev.names == host.names == ["a", "b", "c", "Overall"]
+    for x, y in zip(dev.psm, host.psm):
+        assert np.array_equal(x, y)
+
+
 def test_allgather_samples_through_the_c_abi(pkg, O):
     """the one collective of the path behind the C ABI (pmdi_comm_*, pmdi_allgather_samples), here in its
     one-rank form on the one GPU of the test box (both ways of forming the communicator), feeding the PSM counts:

@@ -123,3 +123,70 @@ def test_bench_byte_models():
                  + n * 4 + n_s)                                                            # output
     assert b.algorithmic_bytes(w, P, n, n1, work, stats) == C * per_chain
     assert b.algorithmic_bytes(w, P, n, n1, work, stats, layout="particle") > C * per_chain
+
+
+def _literal_generate_psm(path, burnin, thin):
+    """src/output_analysis/consensus_map.jl:31-65, line by line, in numpy (1-based arithmetic kept)."""
+    from math import comb
+    lines = [ln for ln in open(path).read().split("\n") if ln]
+    names = lines[0].split(",")
+    output = np.array([[float(x) for x in ln.split(",")] for ln in lines[burnin + 1:]])
+    K = sum("MassParameter" in s for s in names)
+    first = K + comb(K, 2) + (K == 1) + 2                      # 1-based first allocation column
+    output = output[::thin, first - 1:]
+    n_obs = output.shape[1] / K
+    assert n_obs % 1 == 0
+    n_obs, n_iter = int(n_obs), output.shape[0]
+    psm = [np.eye(n_obs) for _ in range(K + (K > 1))]
+    uniq = []
+    for x in names[first - 1:]:
+        if x.split("_")[0] not in uniq:
+            uniq.append(x.split("_")[0])
+    for k in range(1, K + 1):
+        for j in range(1, n_obs):
+            for i in range(j + 1, n_obs + 1):
+                psm[k - 1][i - 1, j - 1] = np.sum(output[:, i + n_obs * (k - 1) - 1] == output[:, j + n_obs * (k - 1) - 1]) / n_iter
+    if K > 1:
+        for k in range(K):
+            psm[K] += psm[k] / K
+        psm[K][np.diag_indices(n_obs)] = 1.0
+    return psm, uniq + (["Overall"] if K > 1 else [])
+
+
+@pytest.mark.parametrize("K,burnin,thin", [(1, 0, 1), (2, 3, 2), (3, 1, 3)])
+def test_generate_psm_reads_the_output_file_like_the_reference(pkg, tmp_path, K, burnin, thin):
+    """SURVEY 8 f3/f4, reader side: file written by the native writer -> native reader (header, burn-in, thinning, the column
+    offset with its K == 1 special case, names) -> PSM; against consensus_map.jl:31-65 restated literally."""
+    from particlemdi_jl_amd.psm import generate_psm
+    rng = np.random.default_rng(K)
+    n, iters, N = 9, 14, 4
+    names = ["alpha", "beta", "gamma"][:K]
+    path = tmp_path / "out.csv"
+    w = pkg.CsvWriter(path, K, n, data_names=names)
+    rows = []
+    for _ in range(iters):
+        s = rng.integers(1, N + 1, size=(n, K))
+        rows.append(s)
+        w.row(rng.gamma(2.0, 1.0, K), rng.gamma(1.0, 1.0, max(1, K * (K - 1) // 2)), -123.5, s)
+    w.close()
+    smp, nm = pkg.read_allocations(path, burnin, thin)
+    want = np.stack(rows[burnin::thin]).transpose(0, 2, 1)
+    assert smp.shape == want.shape and (smp == want).all() and nm == names
+    got = generate_psm(str(path), burnin, thin, host=True)
+    ref, ref_names = _literal_generate_psm(path, burnin, thin)
+    assert got.names == ref_names and len(got.psm) == len(ref)
+    for a, b in zip(got.psm, ref):
+        assert np.array_equal(a, b)
+
+
+def test_read_allocations_rejects_what_the_reference_rejects(pkg, tmp_path):
+    p = tmp_path / "bad.csv"
+    p.write_text("MassParameter_1,MassParameter_2,phi_1_2,ll,a_n1,a_n2,b_n1\n1.0,1.0,0.5,-3.0,1.0,2.0,1.0\n")
+    with pytest.raises(pkg.PmdiError, match="different number of observations"):      # consensus_map.jl:41
+        pkg.read_allocations(p)
+    p.write_text("MassParameter_1,phi_1_1,ll,a_n1,a_n2\n1.0,0.5,-3.0,1.5,2.0\n")
+    with pytest.raises(pkg.PmdiError, match="not a label"):
+        pkg.read_allocations(p)
+    p.write_text("MassParameter_1,phi_1_1,ll,a_n1,a_n2\n1.0,0.5,-3.0,1.0\n")
+    with pytest.raises(pkg.PmdiError, match="fields"):
+        pkg.read_allocations(p)
