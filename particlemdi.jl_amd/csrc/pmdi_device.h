@@ -46,6 +46,77 @@ template <class Tp> __device__ __forceinline__ Tp *gen(PMDI_GLOBAL Tp *p) { retu
 __device__ __forceinline__ double2 ld2(const PMDI_GLOBAL dbl2v *p, size_t i) { const dbl2v v = p[i]; return make_double2(v.x, v.y); }
 __device__ __forceinline__ void st2(PMDI_GLOBAL dbl2v *p, size_t i, double2 v) { dbl2v w; w.x = v.x; w.y = v.y; p[i] = w; }
 
+#if defined(PMDI_EXP_LAZY_KS) && defined(PMDI_SWEEP_TU)
+// EXPERIMENT (default off; the default build is instruction-identical without it -- checked by diffing the assembly).
+// The 22 pointers of a KS are wave-uniform, but the step loop cannot keep them in SGPRs: make_ks() at the top of every step
+// computes them, the register allocator parks them in VGPRs and spills those -- 22 scratch stores per lane and step in the
+// 256-register build (hipcc -gline-tables-only -S: every scratch_store of the step loop sits on make_ks' lines), i.e. ~22 KB
+// of the ~50 KB of spill write-back per chain and step (profiles/README.md), and a scratch reload in front of every phase.
+// Here a field is a (dataset, chain) pair and the address is rebuilt where it is used, from scalar loads of the argument
+// block (the asm keeps the loads from being hoisted back out of the step loop).
+__device__ __forceinline__ const DsetDev *opaque_ds(const DsetDev *d)
+{
+    // wave-uniform by construction (argument block + blockIdx-derived dataset index); out-of-line device functions receive
+    // their arguments in VGPRs, so say so explicitly
+    const unsigned long long v = (unsigned long long)d;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (const DsetDev *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+template <class Tp, size_t DsetDev::*OFF>
+struct LazyArr {
+    const DsetDev *d;
+    int chain;
+    __device__ __forceinline__ PMDI_GLOBAL Tp *p() const
+    {
+        const DsetDev *dd = opaque_ds(d);
+        return glob((Tp *)(dd->arena + (size_t)chain * dd->stride + dd->*OFF));
+    }
+    __device__ __forceinline__ operator PMDI_GLOBAL Tp *() const { return p(); }
+    template <class I> __device__ __forceinline__ PMDI_GLOBAL Tp &operator[](I i) const { return p()[i]; }
+    template <class I> __device__ __forceinline__ PMDI_GLOBAL Tp *operator+(I i) const { return p() + i; }
+};
+struct LazyPart {
+    const DsetDev *d;
+    int chain;
+    __device__ __forceinline__ gint operator[](int cur) const
+    {
+        const DsetDev *dd = opaque_ds(d);
+        return glob((int *)(dd->arena + (size_t)chain * dd->stride + dd->o_particle[cur]));
+    }
+};
+template <class Tp, size_t DsetDev::*OFF> __device__ __forceinline__ PMDI_GLOBAL Tp *raw(const LazyArr<Tp, OFF> &x) { return x.p(); }
+struct KS {
+    LazyPart part;
+    LazyArr<int, &DsetDev::o_pid> pid;
+    LazyArr<int, &DsetDev::o_sid> sid;
+    LazyArr<int, &DsetDev::o_kv> kv;
+    LazyArr<int, &DsetDev::o_newid> newid;
+    LazyArr<int, &DsetDev::o_counts> counts;
+    LazyArr<int, &DsetDev::o_ncop> ncop;
+    LazyArr<int, &DsetDev::o_firstc> firstc;
+    LazyArr<int, &DsetDev::o_cn> cn;
+    LazyArr<int, &DsetDev::o_clslead> clslead;
+    LazyArr<int, &DsetDev::o_clsval> clsval;
+    LazyArr<int, &DsetDev::o_dl> dl;
+    LazyArr<int, &DsetDev::o_col> col;
+    LazyArr<unsigned long long, &DsetDev::o_cgrp> cgrp;
+    LazyArr<double, &DsetDev::o_lp> lp;
+    LazyArr<double, &DsetDev::o_cdf> cdf;
+    LazyArr<dbl2v, &DsetDev::o_ml> ml;
+    LazyArr<dbl2v, &DsetDev::o_sb> sb;
+    LazyArr<int, &DsetDev::o_cnt> cnt;
+    LazyArr<long long, &DsetDev::o_nbs> nbs;
+    LazyArr<unsigned char, &DsetDev::o_sstar> sstar;
+};
+__device__ __forceinline__ KS make_ks(const DsetDev &d, int chain)
+{
+    const DsetDev *dp = &d;
+    return KS{{dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain},
+              {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain}, {dp, chain},
+              {dp, chain}};
+}
+#else
 struct KS {  // pointers of one (chain, dataset)
     gint part[2];
     gint pid, sid, kv, newid, counts, ncop, firstc, cn, clslead, clsval, dl, col;
@@ -85,6 +156,9 @@ __device__ __forceinline__ KS make_ks(const DsetDev &d, int chain)
     s.dl = glob((int *)(b + d.o_dl));
     return s;
 }
+
+#endif
+template <class Tp> __device__ __forceinline__ Tp raw(Tp x) { return x; }   // (a KS field as a plain pointer: identity in the default build)
 
 // ---------------------------------------------------------------------------
 // Block-level primitives (64-wide waves).

@@ -19,6 +19,7 @@
 //     falls back to per-id tables in global memory -- same results, slower.
 //
 // Reference lines are cited as file:line relative to /root/reference.
+#define PMDI_SWEEP_TU 1     // (the default-off KS experiment of pmdi_device.h applies to this file only)
 #include "pmdi_device.h"
 
 using namespace pmdi_dev;
@@ -236,6 +237,30 @@ __device__ __forceinline__ Dual<Tp> dual(bool lds, __attribute__((address_space(
 {
     return Dual<Tp>{l, g, lds};
 }
+#if defined(PMDI_EXP_LAZY_KS)
+// (experiment, default off: pmdi_device.h)  Dual whose global side is rebuilt from the argument block where it is used
+template <class Tp, size_t DsetDev::*OFF>
+struct DualL {
+    __attribute__((address_space(3))) Tp *l;
+    LazyArr<Tp, OFF> g;
+    size_t off;
+    bool lds;
+    struct Ref {
+        const DualL &d;
+        size_t i;
+        __device__ __forceinline__ operator Tp() const { return d.lds ? d.l[i] : d.g.p()[d.off + i]; }
+        __device__ __forceinline__ Tp operator=(Tp v) const { if (d.lds) d.l[i] = v; else d.g.p()[d.off + i] = v; return v; }
+        __device__ __forceinline__ Tp operator+=(Tp v) const { const Tp w = Tp(*this) + v; *this = w; return w; }
+    };
+    __device__ __forceinline__ Ref operator[](size_t i) const { return Ref{*this, i}; }
+    __device__ __forceinline__ DualL operator+(size_t o) const { return DualL{l + o, g, off + o, lds}; }
+};
+template <class Tp, size_t DsetDev::*OFF>
+__device__ __forceinline__ DualL<Tp, OFF> dual(bool lds, __attribute__((address_space(3))) Tp *l, const LazyArr<Tp, OFF> &g)
+{
+    return DualL<Tp, OFF>{l, g, 0, lds};
+}
+#endif
 
 struct ClsList {
     lint l_lead, l_val;
@@ -252,8 +277,8 @@ struct ClsList {
 // Rebuild the class list from pid[]: leader = lowest particle of each class (the particle
 // whose CDF the reference caches in fprob_dict, src/pmdi.jl:225-248).  lead_of must be INF
 // for every class value on entry; it is INF again on exit.  Returns the number of classes.
-template <int T>
-__device__ __forceinline__ int rebuild_classes(const Dual<int> &pidk, const ClsList &cl, const Sh &sh, int P)
+template <int T, class DualT>
+__device__ __forceinline__ int rebuild_classes(const DualT &pidk, const ClsList &cl, const Sh &sh, int P)
 {
     const int tid = threadIdx.x;
     for (int pb = 0; pb < P; pb += T) {
@@ -391,8 +416,8 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         const DsetDev &d = dsb[k];
         const KS s = make_ks(d, chain);
         const int D = d.D;
-        const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
-        const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
+        const auto pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+        const auto colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
         unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
         for (int idx = tid; idx <= cap; idx += T) { s.counts[idx] = 0; s.ncop[idx] = 0; s.firstc[idx] = PMDI_INF_I; }
         for (int idx = tid; idx < N * P; idx += T) { s.newid[idx] = 0; s.cgrp[idx] = 0; }
@@ -563,8 +588,8 @@ __device__ __forceinline__ void stats_update_all(const DsetDev &d, const KS &s, 
 // changes).  Particles of one column that chose the same label move together: such a group takes a copy of the column with
 // that entry replaced -- or the column itself when nobody else stays on it (no particle that does not write, and the first
 // group to ask).  Every live column keeps at least one particle, so there are never more than P of them.
-template <int T, class Wr>
-__device__ __forceinline__ void columns_apply(const Sh &sh, const KS &s, gint tab, const Dual<int> &colk, int k, int N, int P, int tid_,
+template <int T, class DualT, class Wr>
+__device__ __forceinline__ void columns_apply(const Sh &sh, const KS &s, gint tab, const DualT &colk, int k, int N, int P, int tid_,
                                               unsigned epoch, Wr wr)
 {
     const int tid = tid_;
@@ -715,14 +740,14 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     const KS s = make_ks(d, chain);
     const int D = d.D;
     const gint part = s.part[sh.kcur[k]];
-    const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
-    const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
-    const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
-    const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
+    const auto pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+    const auto colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
+    const auto sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
+    const auto kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
     const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
     const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
     const int items = ncls * N;
-    const Dual<double> cdfp = dual(small, sh.cdf, s.cdf);
+    const auto cdfp = dual(small, sh.cdf, s.cdf);
     const DList dl{sh.need, sh.fl_p, s.dl, P, (8 * a.item_cap + 3 * PMDI_DL_LDS) / 3};
     int nd = 0, nclone = 0, new_ncls = 0, failed = 0;
     (void)items;
@@ -760,7 +785,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
                         bool fresh = false;
                         if (valid) {
                             const int cls = pidk[p];
-                            const Dual<double> row = cdfp + (size_t)sh.slot_of[cls] * (N + 2);
+                            const auto row = cdfp + (size_t)sh.slot_of[cls] * (N + 2);
                             if (p != 0) {
                                 const double u = uniform01(seed, iter, (unsigned)pos, (unsigned)(kd0 + k), (unsigned)p, SITE_DRAW);
                                 for (int t = 0; t < N - 1; ++t) {
@@ -1044,7 +1069,7 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             for (int p = tid; p < P; p += T) sh.lw[p] = 1.0;     // src/pmdi.jl:319
             __syncthreads();
             // ancestor of every slot after the conditional-SMC fix-up (slot 0 keeps particle 0)
-            const Dual<int> ancp = dual(a.pp_lds != 0, sh.kv, make_ks(dsb[0], chain).kv);
+            const auto ancp = dual(a.pp_lds != 0, sh.kv, make_ks(dsb[0], chain).kv);
             for (int p = tid; p < P; p += T) ancp[p] = (p == 0) ? 0 : (p <= js ? pstar_raw[p - 1] : pstar_raw[p]);
             __syncthreads();
             if (a.q2) {
@@ -1063,12 +1088,12 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
                 const int D = d.D;
                 const int cur = sh.kcur[k];
                 const int oldmax = sh.kmaxid[k];
-                const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
-                const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
+                const auto pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+                const auto sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
                 const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
                 const gcint src = s.part[cur];
                 const gint dst = s.part[cur ^ 1];
-                const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
+                const auto colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
                 const int ncol_old = sh.kncol[k];
                 // The gather particle[:, partstar, k] (:322) by column: a particle takes its ancestor's column INDEX; the columns
                 // that still have a particle are compacted into the other buffer, relabelled on the way (:331-337).  Occupancy
@@ -1406,10 +1431,10 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             const int ncls = sh.kncls[k];
             const int cur = sh.kcur[k];
             const gint part = s.part[cur];
-            const Dual<int> pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
-            const Dual<int> colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
-            const Dual<int> sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
-            const Dual<int> kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
+            const auto pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+            const auto colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
+            const auto sidp = dual(a.pp_lds != 0, sh.sid, s.sid);
+            const auto kvp = dual(a.pp_lds != 0, sh.kv, s.kv);
             const unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
             const double *pik = gen(sh.pis + k * N);
             const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
@@ -1528,7 +1553,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // wave; max / cumsum / normalise by shuffles.  The cumsum follows Julia's
             // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
             PH(4); FRESH_LANE_IDS();
-            const Dual<double> cdfp = dual(small, sh.cdf, s.cdf);
+            const auto cdfp = dual(small, sh.cdf, s.cdf);
             if (N > 64) {
                 // 64 < N <= 128: one class per wave, the labels in two chunks of 64 lanes (same arithmetic, same order:
                 // c[n] = e[0] + (e[1] + ... + e[n]) is Julia's accumulate_pairwise! for fewer than 129 elements)
