@@ -142,11 +142,13 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.knflag = take(PMDI_KMAX_I * 4);
     c.khint = take(PMDI_KMAX_I * 4);
     c.kncol = take(PMDI_KMAX_I * 4);
+#ifndef PMDI_EXP_LEAF_ALIAS
     c.leaf_i1 = take(64 * 4);
     c.leaf_n = take(64 * 4);
     c.leaf_tot = take(64 * 8);
     c.leaf_carry = take(64 * 8);
     c.leaf_prog = take(256);
+#endif
     c.dl_slot = take((size_t)PMDI_DL_LDS * 4);
     c.h1k = take((size_t)PMDI_HT_SIZE * 4);
     c.h1a = take((size_t)PMDI_HT_SIZE * 4);
@@ -163,6 +165,9 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     const int KL = a.ksplit ? 1 : a.K;                       // datasets this workgroup sweeps
     c.lpl = take(icap * 8);
     c.cdf = take((2 * icap + 4) * 8);                        // rows of N + 2: CDF, log-increment, one-hot label
+#ifdef PMDI_EXP_LEAF_ALIAS                                   // (experiment: the CDF rows are idle during a resampling event)
+    c.leaf_i1 = c.cdf; c.leaf_n = c.cdf + 256; c.leaf_tot = c.cdf + 512; c.leaf_carry = c.cdf + 1024; c.leaf_prog = c.cdf + 1536;
+#endif
     c.need = take(icap * 4);
     c.need_slot = take(icap * 4);
     c.item_id = take(icap * 4);
@@ -374,6 +379,39 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
 // hoisted across the whole sweep loop and spill the hot path's registers).  Each one rebuilds
 // its view of the arguments and of the LDS table.
 
+// (the leaf decomposition of the resampling cumsum, as a macro: built once per sweep in the prefix -- or, in the default-off
+// experiment PMDI_EXP_LEAF_ALIAS, at every resampling event into tables that share the CDF rows' LDS: 1.8 KB less, which is
+// what keeps the class ids and the column indices from both fitting the two-per-CU budget at cfg2)
+#define PMDI_BUILD_LEAF_PROGRAM()                                                                       \
+    do {                                                                                                \
+            int nl = 0, np = 0, sp = 0;                                                                 \
+            int st_i1[24], st_n[24], st_stage[24];                                                      \
+            bool ok = P > 1;                                                                            \
+            if (ok) { st_i1[0] = 1; st_n[0] = P - 1; st_stage[0] = 0; }                                 \
+            while (ok && sp >= 0) {                                                                     \
+                const int i1 = st_i1[sp], nn = st_n[sp];                                                \
+                if (nn < 128) {                                                                         \
+                    if (nl >= 64 || np >= 255) { ok = false; break; }                                   \
+                    sh.leaf_i1[nl] = i1; sh.leaf_n[nl] = nn; ++nl;                                      \
+                    sh.leaf_prog[np++] = 0; --sp;                                                       \
+                } else if (st_stage[sp] == 0) {                                                         \
+                    if (np >= 255) { ok = false; break; }                                               \
+                    st_stage[sp] = 1; sh.leaf_prog[np++] = 3;                                           \
+                    ++sp; st_i1[sp] = i1; st_n[sp] = nn >> 1; st_stage[sp] = 0;                         \
+                } else if (st_stage[sp] == 1) {                                                         \
+                    if (np >= 255) { ok = false; break; }                                               \
+                    st_stage[sp] = 2; sh.leaf_prog[np++] = 1;                                           \
+                    const int n2 = nn >> 1;                                                             \
+                    ++sp; st_i1[sp] = i1 + n2; st_n[sp] = nn - n2; st_stage[sp] = 0;                    \
+                } else {                                                                                \
+                    if (np >= 255) { ok = false; break; }                                               \
+                    sh.leaf_prog[np++] = 2; --sp;                                                       \
+                }                                                                                       \
+            }                                                                                           \
+            sh.misc[M_NLEAF] = ok ? nl : 0;                                                             \
+            sh.misc[M_NPROG] = ok ? np : 0;                                                             \
+    } while (0)
+
 // reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207)
 template <int T>
 __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
@@ -383,32 +421,9 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         // leaf decomposition of Julia's accumulate_pairwise! over [1, P) and its recursion as a
         // post-order program (0 leaf, 3 descend left, 1 left done -> right, 2 node done), used by
         // the resampling cumsum.  More than 64 leaves (P > ~4096): the serial form is used.
-        int nl = 0, np = 0, sp = 0;
-        int st_i1[24], st_n[24], st_stage[24];
-        bool ok = P > 1;
-        if (ok) { st_i1[0] = 1; st_n[0] = P - 1; st_stage[0] = 0; }
-        while (ok && sp >= 0) {
-            const int i1 = st_i1[sp], nn = st_n[sp];
-            if (nn < 128) {
-                if (nl >= 64 || np >= 255) { ok = false; break; }
-                sh.leaf_i1[nl] = i1; sh.leaf_n[nl] = nn; ++nl;
-                sh.leaf_prog[np++] = 0; --sp;
-            } else if (st_stage[sp] == 0) {
-                if (np >= 255) { ok = false; break; }
-                st_stage[sp] = 1; sh.leaf_prog[np++] = 3;
-                ++sp; st_i1[sp] = i1; st_n[sp] = nn >> 1; st_stage[sp] = 0;
-            } else if (st_stage[sp] == 1) {
-                if (np >= 255) { ok = false; break; }
-                st_stage[sp] = 2; sh.leaf_prog[np++] = 1;
-                const int n2 = nn >> 1;
-                ++sp; st_i1[sp] = i1 + n2; st_n[sp] = nn - n2; st_stage[sp] = 0;
-            } else {
-                if (np >= 255) { ok = false; break; }
-                sh.leaf_prog[np++] = 2; --sp;
-            }
-        }
-        sh.misc[M_NLEAF] = ok ? nl : 0;
-        sh.misc[M_NPROG] = ok ? np : 0;
+#ifndef PMDI_EXP_LEAF_ALIAS
+        PMDI_BUILD_LEAF_PROGRAM();
+#endif
     }
     __syncthreads();
     // ---- reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207) ----
@@ -967,6 +982,9 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             const double u01 = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
             const double usl = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
             double *wb = gen(sh.term);
+#ifdef PMDI_EXP_LEAF_ALIAS
+            if (tid == 0) PMDI_BUILD_LEAF_PROGRAM();
+#endif
             for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
             __syncthreads();
             PHR(0);   // weights
