@@ -317,7 +317,7 @@ def main():
             "burnin_iters_per_sec": (burnin * C * world / burnin_s) if burnin else None,
             "sweep_kernel_ms": kernel_ms,
             "sweep_only_iters_per_sec": C * world / (kernel_ms * 1e-3),
-            "chain_slot_busy_frac": float(chain_s.sum() / (min(C * (K if sw.split else 1), (2 if sw.lds_bytes <= 80 * 1024 else 1) * 256) * kernel_ms * 1e-3))
+            "chain_slot_busy_frac": float(chain_s.sum() / (min(C * (K if sw.split else 1), (2 if sw.lds_bytes <= 80 * 1024 - 256 else 1) * 256) * kernel_ms * 1e-3))
             if not sw.split else None,
             "per_chain_iters_per_sec": {"p50": float(1.0 / np.median(chain_s)), "slowest": float(1.0 / chain_s.max()),
                                         "fastest": float(1.0 / chain_s.min()),
