@@ -190,3 +190,17 @@ def test_read_allocations_rejects_what_the_reference_rejects(pkg, tmp_path):
     p.write_text("MassParameter_1,phi_1_1,ll,a_n1,a_n2\n1.0,0.5,-3.0,1.0\n")
     with pytest.raises(pkg.PmdiError, match="fields"):
         pkg.read_allocations(p)
+
+
+def test_read_allocations_line_endings_and_short_files(pkg, tmp_path):
+    p = tmp_path / "crlf.csv"
+    p.write_bytes(b"MassParameter_1,phi_1_1,ll,a_n1,a_n2\r\n1.0,0.5,-3.0,1.0,2.0\r\n\r\n2.0,0.25,-2.0,2.0,2.0")      # CRLF, blank line, no final newline
+    smp, names = pkg.read_allocations(p)
+    assert names == ["a"] and smp.tolist() == [[[1, 2]], [[2, 2]]]
+    smp, _ = pkg.read_allocations(p, burnin=1, thin=5)
+    assert smp.tolist() == [[[2, 2]]]
+    smp, _ = pkg.read_allocations(p, burnin=7)
+    assert smp.shape == (0, 1, 2)
+    from particlemdi_jl_amd.psm import generate_psm
+    with pytest.raises(ValueError, match="no rows left"):
+        generate_psm(str(p), burnin=7, host=True)
