@@ -1498,7 +1498,90 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             if (!small) {
                 PH(2); FRESH_LANE_IDS();
                 sweep_logprob_all<T>(ap, k, maxid);
-            } else {
+            }
+#ifdef PMDI_EXP_WAVE_SUM
+            // EXPERIMENT (default off): D <= 64 -- one wave per needed cluster, a lane per feature; the per-feature terms stay in
+            // registers and the wave adds them in feature order through v_readlane (same terms, same order as the LDS-staged form:
+            // bit-identical), two clusters per wave at a time so that their pool reads and their two chains of dependent adds
+            // overlap.  Replaces the terms pass, a barrier and the one-lane-per-cluster ordered sums (9 k of a 41 k-cycle step at HL).
+            else if (D <= 64) {
+                PH(2); FRESH_LANE_IDS();
+                const int q = lane;
+                const bool qon = q < D && flk[q] != 0;
+                const unsigned long long onmask = __ballot(qon);
+                constexpr int NW = T / 64;
+                for (int j = wave; j < nneed; j += 2 * NW) {
+                    int id_[2], cn_[2];
+                    double ta_[2] = {0.0, 0.0}, tb_[2] = {0.0, 0.0};
+                    bool have_[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        have_[u] = j + u * NW < nneed;
+                        id_[u] = have_[u] ? sh.need[j + u * NW] : 1;
+                        cn_[u] = have_[u] ? (int)s.cn[id_[u]] : 0;
+                    }
+                    if (d.kind == K_GAUSSIAN) {
+                        double2 sb_[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) sb_[u] = (have_[u] && qon) ? ld2(s.sb, (size_t)id_[u] * D + q) : make_double2(0.0, 0.5);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (have_[u] && qon) gauss_terms(sh.xs[q], (double)cn_[u], gauss_ml(cn_[u], sb_[u]), ta_[u], tb_[u]);
+                    } else if (d.kind == K_CATEGORICAL) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (have_[u] && qon) {
+                                const int x = ((const int *)sh.xs)[q];
+                                ta_[u] = glob(d.lhtab)[glob(d.maxcol)[q] + 2 * cn_[u]];                 // log(nlevels_q + n)
+                                const int c = s.cnt[((size_t)id_[u] * D + q) * d.L + (x - 1)];
+                                tb_[u] = (cn_[u] == 0) ? glob(d.lhtab)[1] : glob(d.lhtab)[2 * c + 1];   // log(0.5 + counts)
+                            }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (have_[u] && qon) ta_[u] = negbin_term(glob(d.lgtab), cn_[u], ((const int *)sh.xs)[q], s.nbs[(size_t)id_[u] * D + q]);
+                    }
+                    // the ordered sums (calc_logprob's loops), wave-uniform
+                    double out_[2];
+                    if (d.kind == K_GAUSSIAN) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) out_[u] = (double)nflag * glob(d.gtab)[cn_[u]];      // gaussian_cluster.jl:38-40
+                        for (int qq = 0; qq < D; ++qq)
+                            if ((onmask >> qq) & 1ull) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) { out_[u] += readlane_f64(ta_[u], qq); out_[u] -= readlane_f64(tb_[u], qq); }
+                            }
+                    } else if (d.kind == K_CATEGORICAL) {
+                        double acc_[2] = {0.0, 0.0};                                                     // categorical_cluster.jl:30
+                        for (int qq = 0; qq < D; ++qq)
+                            if ((onmask >> qq) & 1ull) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) acc_[u] += readlane_f64(ta_[u], qq);
+                            }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) out_[u] = -acc_[u];
+                        for (int qq = 0; qq < D; ++qq)
+                            if ((onmask >> qq) & 1ull) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) out_[u] += readlane_f64(tb_[u], qq);
+                            }
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) out_[u] = 0.0;                                       // negbinom_cluster.jl:25
+                        for (int qq = 0; qq < D; ++qq)
+                            if ((onmask >> qq) & 1ull) {
+#pragma unroll
+                                for (int u = 0; u < 2; ++u) out_[u] += readlane_f64(ta_[u], qq);
+                            }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (have_[u] && lane == 0) sh.lpl[j + u * NW] = out_[u];
+                }
+                lds_barrier();
+            }
+#endif
+            else {
                 const int RS = 2 * D + 1, D1 = D + 1;
                 int CH = a.terms_cap / RS;
                 if (CH < 1) CH = 1;

@@ -9,6 +9,10 @@ Then, on the GPU box, run the variants back to back in one gpurun call (same box
         python scripts/bline.py $v < gpurun_out/ab.json
     done
 
+Default-off experiments waiting for their first GPU run (round 3): -DPMDI_EXP_LAZY_KS, -DPMDI_EXP_WAVE_SUM, -DPMDI_EXP_LEAF_ALIAS
+(DESIGN.md section 9); each must pass `pytest tests/test_gpu_sweep.py tests/test_gpu_soak.py -m gpu` with PMDI_LIB_PATH set before its
+bench number means anything.
+
 PMDI_NO_BUILD=1 keeps the box from rebuilding a variant from the (different) sources that travelled with it.  build_ab/ is
 git-ignored but travels with gpurun.  (Round 2: column table 469.8 / +uniform log-weights 465.4 / +LDS mirrors 442.1 it/s.)
 """
