@@ -1842,6 +1842,26 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 // label and all others the one-hot label -- the hand-off is a 16-byte header, no per-particle records
                 const bool hdr_only = XSPLIT && one && (int)sh.cdf[N + 1] >= 0;
                 if (hdr_only) xhdr = 1 | ((int)sh.cdf[N + 1] << 8);
+#ifdef PMDI_EXP_COLVOTE
+                // EXPERIMENT (default off): one class whose CDF row is one-hot at the reference label -> every particle takes that
+                // label; if every live column holds the same cluster under it (ncol table reads instead of a column index and a
+                // table entry per particle) the step is unanimous without looking at a particle: no draw loop, no second vote.
+                bool colsame = false;
+                if (one && (int)sh.cdf[N + 1] == ns0) {
+                    const int ncol = sh.kncol[k];
+                    int okc = 1;
+                    for (int c = tid; c < ncol; c += T) okc &= (part[(size_t)c * N + ns0] == c0) ? 1 : 0;
+                    colsame = __syncthreads_and(okc) != 0;
+                }
+                if (colsame) {
+                    const double inc = sh.cdf[N];                        // the class's log-increment (:227,:245)
+                    for (int p = tid; p < P; p += T) {
+                        if (!XSPLIT) sh.lw[p] = sh.lw[p] + inc;          // (split mode: the header alone carries this step, hdr_only)
+                        sh.news[k * P + p] = (unsigned char)ns0;
+                        s.sstar[(size_t)pos * P + p] = (unsigned char)ns0;   // (:265)
+                    }
+                } else
+#endif
                 for (int pb0 = 0; pb0 < P; pb0 += 4 * T) {       // four particles per lane, stage by stage: their
                     int ns_[4], c_[4], r_[4];                    // LDS chains and pool reads overlap
                     double inc_[4], lw_[4];
@@ -1903,7 +1923,11 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 if (freshk) v = 1;                                           // curr_id += 1 (:267-269)
                 const bool needs = s.counts[c0] != P;                        // ncopies == counts ? (:286)
                 const int nnew = s.cn[c0] + 1;
+#ifdef PMDI_EXP_COLVOTE
+                ustep = colsame ? true : (__syncthreads_and(same) != 0);
+#else
                 ustep = __syncthreads_and(same) != 0;
+#endif
                 if (ustep) {
                     PH(13);
                     const int tgt = needs ? maxid + 1 : c0;                  // (:290-292)

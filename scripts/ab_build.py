@@ -9,7 +9,7 @@ Then, on the GPU box, run the variants back to back in one gpurun call (same box
         python scripts/bline.py $v < gpurun_out/ab.json
     done
 
-Default-off experiments waiting for their first GPU run (round 3): -DPMDI_EXP_LAZY_KS, -DPMDI_EXP_WAVE_SUM, -DPMDI_EXP_LEAF_ALIAS
+Default-off experiments waiting for their first GPU run (round 3): -DPMDI_EXP_LAZY_KS, -DPMDI_EXP_WAVE_SUM, -DPMDI_EXP_COLVOTE, -DPMDI_EXP_LEAF_ALIAS
 (DESIGN.md section 9); each must pass `pytest tests/test_gpu_sweep.py tests/test_gpu_soak.py -m gpu` with PMDI_LIB_PATH set before its
 bench number means anything.
 
