@@ -54,14 +54,15 @@ __device__ __forceinline__ void st2(PMDI_GLOBAL dbl2v *p, size_t i, double2 v) {
 // of the ~50 KB of spill write-back per chain and step (profiles/README.md), and a scratch reload in front of every phase.
 // Here a field is a (dataset, chain) pair and the address is rebuilt where it is used, from scalar loads of the argument
 // block (the asm keeps the loads from being hoisted back out of the step loop).
-__device__ __forceinline__ const DsetDev *opaque_ds(const DsetDev *d)
+typedef const __attribute__((address_space(4))) DsetDev *cdsptr;   // the argument block through the constant address space: s_load
+__device__ __forceinline__ cdsptr opaque_ds(const DsetDev *d)
 {
     // wave-uniform by construction (argument block + blockIdx-derived dataset index); out-of-line device functions receive
     // their arguments in VGPRs, so say so explicitly
     const unsigned long long v = (unsigned long long)d;
     unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     asm volatile("" : "+s"(lo), "+s"(hi));
-    return (const DsetDev *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+    return (cdsptr)(((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 template <class Tp, size_t DsetDev::*OFF>
 struct LazyArr {
@@ -69,7 +70,7 @@ struct LazyArr {
     int chain;
     __device__ __forceinline__ PMDI_GLOBAL Tp *p() const
     {
-        const DsetDev *dd = opaque_ds(d);
+        const cdsptr dd = opaque_ds(d);
         return glob((Tp *)(dd->arena + (size_t)chain * dd->stride + dd->*OFF));
     }
     __device__ __forceinline__ operator PMDI_GLOBAL Tp *() const { return p(); }
@@ -81,7 +82,7 @@ struct LazyPart {
     int chain;
     __device__ __forceinline__ gint operator[](int cur) const
     {
-        const DsetDev *dd = opaque_ds(d);
+        const cdsptr dd = opaque_ds(d);
         return glob((int *)(dd->arena + (size_t)chain * dd->stride + dd->o_particle[cur]));
     }
 };

@@ -6,7 +6,9 @@ every scratch_store / scratch_load of the chosen builds to its source line.
 Round 2: in the 256-register build `<256,2,false>` 22 of the 36 scratch stores sit on make_ks() (pmdi_device.h) -- the 22
 wave-uniform pointers of a (chain, dataset), computed at the top of EVERY step and parked in scratch: 22 stores x 256 lanes x
 4 B = 22 KB per chain and step, about half of the spill write-back that dominates WRITE_SIZE (profiles/README.md).  With
--DPMDI_EXP_LAZY_KS (addresses rebuilt from the argument block where they are used) the kernel body has 3 stores / 3 loads.
+-DPMDI_EXP_LAZY_KS (addresses rebuilt from the argument block where they are used) the kernel body has 5 stores / 6 loads.
+(Its first version loaded the argument block through a generic pointer: 4 000 extra flat_load instructions instead of s_load --
+caught by the instruction-class line below, fixed by going through the constant address space.)
 """
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +39,12 @@ for line in text:
     if cur and re.match(r"\s+scratch_(store|load)", line):
         f = os.path.basename(files.get(loc[0], "?")) if loc else "?"
         hist[cur][(f, loc[1] if loc else 0, "st" if "scratch_store" in line else "ld")] += 1
+cls = collections.Counter()
+for line in text:       # instruction classes of the whole translation unit: a variant that turns scalar loads into flat loads shows here
+    m = re.match(r"\s+(flat|global|scratch|s_load|ds|buffer)_", line) or re.match(r"\s+(s_load)", line)
+    if m:
+        cls[m.group(1)] += 1
+print("instruction classes (all builds of the file):", dict(cls))
 for fn, h in hist.items():
     if not any(t in fn for t in ("sweep_kernelILi256ELi2ELb0", "sweep_kernelILi512ELi4ELb0", "sweep_resampleILi256", "sweep_resampleILi512")):
         continue
