@@ -48,6 +48,6 @@ def test_spill_budget_of_the_sweep_kernel_builds():
 
 def test_the_lazy_address_experiment_still_builds_and_spills_less():
     """-DPMDI_EXP_LAZY_KS (pmdi_device.h; default off, first A/B of the next round): the per-(chain, dataset) array addresses are
-    rebuilt where they are used instead of being parked in scratch at the top of every step.  Measured 176 / 68 / 11."""
+    rebuilt where they are used instead of being parked in scratch at the top of every step.  Measured 160 / 71 / 11."""
     spills = _spills(["-DPMDI_EXP_LAZY_KS"])
     assert spills["ILi256ELi2ELb1"] <= 15 and spills["ILi512ELi4ELb1"] <= 190
