@@ -113,6 +113,39 @@ def oracle_chain(w, state, n_iter, seed, progress=False):
     return out
 
 
+def parity_check(pkg, w, g, sw, chain, seed, fsel):
+    """Outside the timed region: ONE more iteration of the device-resident chains, and chain `chain` of it re-run through the
+    oracle (the checker) from the same post-hyper-update state, same Philox key, same iteration number: allocations and the
+    picked particle must be equal, the log-weights within the north-star tolerance.  Returns the JSON fragment."""
+    O = G.load_oracle()
+    n, N, K, P = w["n"], w["N"], w["K"], w["P"]
+    g.step(pkg.STEP_BEGIN); g.step(pkg.STEP_HYPERS)
+    st1 = g.get(chain)
+    g.step(pkg.STEP_SWEEP)
+    res = g.results()
+    s_dev = g.get(chain)["s"]                       # before the label alignment: s = sstar[p_star, :, :]
+    if fsel:
+        g.step(pkg.STEP_FEATSEL)
+    g.step(pkg.STEP_ALIGN)
+    it = g.iterations
+    Pi = st1["gamma"] / st1["gamma"].sum(axis=0, keepdims=True)
+    flags = [st1["flags"][sum(w["D"][:k]):sum(w["D"][:k + 1])] for k in range(K)]
+    orc = O.Oracle(w["data"], w["kinds"], N, P, seed=seed + chain)
+    ro = orc.sweep(it, st1["s"], st1["order"], g.n1, Pi, st1["Phi"], flags, lw_init=1.0)
+    orc.close()
+    same_s = bool((s_dev == ro["s"]).all())
+    same_p = int(res["p_star"][chain]) == int(ro["p_star"])
+    same_counters = all(int(res["stats"][chain, j]) == int(ro["stats"][key])
+                        for j, key in enumerate(("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")))
+    lw_ok = bool(np.allclose(res["logweight"][chain], ro["logweight"], rtol=1e-6, atol=1e-6))
+    ok = same_s and same_p and same_counters and lw_ok
+    return {"parity_check": "ok" if ok else "FAILED",
+            "parity_check_detail": {"chain": int(chain), "iteration": int(it), "allocations_equal": same_s, "p_star_equal": same_p,
+                                    "counters_equal": same_counters, "logweights_within_1e-6": lw_ok,
+                                    "oracle_sweep_seconds": float(ro["stats"]["seconds"]),
+                                    "note": "one timed-state chain re-run through the CPU oracle (checker only) outside the timed region"}}
+
+
 def host_core_share():
     """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each
     tenant a share of a large host: 256 hardware threads visible, 16 cores' worth of quota)."""
@@ -183,6 +216,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n of the workload (debug only)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of one timed-state chain (outside the timed region)")
     ap.add_argument("--no-latency-form", action="store_true", help="skip the split-form leg (K > 1)")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="wall-time budget of the CPU baseline leg")
     ap.add_argument("--verbose", action="store_true")
@@ -269,9 +303,15 @@ def main():
         iteration(events)
         g.pack_samples(samples.data_ptr() + k * per, sp)       # retained allocation sample of this iteration (uint8): the PSM's input
     torch.cuda.synchronize()
+    allgather_ms = None
     if comm is not None:
         gathered = torch.empty((world,) + tuple(samples.shape), dtype=torch.uint8, device=dev)
+        ag0, ag1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ag0.record(stream)
         comm.allgather(samples.data_ptr(), gathered.data_ptr(), samples.numel(), sp)      # RCCL over xGMI: the PSM's input
+        ag1.record(stream)
+        torch.cuda.synchronize()
+        allgather_ms = float(ag0.elapsed_time(ag1))       # inside the timed region; reported on its own so that sampling and exchange separate
     barrier()
     dt = time.perf_counter() - t0
     res = g.results()
@@ -316,6 +356,7 @@ def main():
             "obs_particles_per_sec": total_iters * n_s * P / dt,
             "burnin_iters_per_sec": (burnin * C * world / burnin_s) if burnin else None,
             "sweep_kernel_ms": kernel_ms,
+            "allgather_ms": allgather_ms, "allgather_bytes_per_rank": (int(samples.numel()) if allgather_ms is not None else None),
             "sweep_only_iters_per_sec": C * world / (kernel_ms * 1e-3),
             "chain_slot_busy_frac": float(chain_s.sum() / (min(C * (K if sw.split else 1), (2 if sw.lds_bytes <= 80 * 1024 - 256 else 1) * 256) * kernel_ms * 1e-3))
             if not sw.split else None,
@@ -346,6 +387,12 @@ def main():
         comm.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and not args.no_parity and args.workload != "cfg5":
+        # ---- parity of the timed kernel instantiation, outside the timed region (cfg5: the oracle needs minutes per sweep)
+        out.update(parity_check(pkg, w, g, sw, int(np.argsort(costs)[C // 2]), seed, False))
+        if out["parity_check"] != "ok":
+            print(json.dumps(out))
+            raise SystemExit("bench: the timed kernel's results differ from the oracle's: " + json.dumps(out["parity_check_detail"]))
     if rank == 0 and K > 1 and not args.no_latency_form and not sw.split:
         # ---- the latency form on settled chains of this run: K cooperating workgroups per chain, as many chains as are resident at once
         order_c = np.argsort(costs)

@@ -59,6 +59,10 @@ def lib():
     L.pmdi_oracle_feature_select.argtypes = [vp, i64, vp, vp, vp]
     L.pmdi_oracle_work.restype = None
     L.pmdi_oracle_work.argtypes = [vp, vp, vp]
+    L.pmdi_oracle_debug_steps.restype = C.c_int
+    L.pmdi_oracle_debug_steps.argtypes = [vp, vp]
+    L.pmdi_oracle_debug_columns.restype = None
+    L.pmdi_oracle_debug_columns.argtypes = [vp, vp]
     L.pmdi_oracle_export.restype = C.c_int
     L.pmdi_oracle_export.argtypes = [vp, vp, vp, vp, vp]
     L.pmdi_oracle_cluster_new.restype = vp
@@ -200,6 +204,18 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"pmdi_oracle_feature_select failed rc={rc}")
         return flags, probs
+
+    def debug_steps(self, n_swept):
+        """Switch the per-step record on: returns the (n_swept, K, 8) int64 array the next sweeps fill
+        (columns documented at pmdi_oracle_debug_steps in pmdi_oracle.c); debug_steps(0) switches it off."""
+        if not n_swept:
+            self.L.pmdi_oracle_debug_steps(self.h, None)
+            self._dbg = None
+            return None
+        self._dbg = np.zeros((int(n_swept), self.K, 8), dtype=np.int64)
+        if self.L.pmdi_oracle_debug_steps(self.h, _ptr(self._dbg)) != 0:
+            raise MemoryError("pmdi_oracle_debug_steps")
+        return self._dbg
 
     def work(self):
         """(updates[K], moved[K]) of the last sweep: cluster_add! calls (:300), renumbering deepcopies (:336)."""

@@ -375,6 +375,8 @@ struct pmdi_oracle {
     int64_t *maxid;         /* [k] running maximum(particle_k) */
     int64_t last_updates[8], last_moved[8];   /* per dataset, last sweep: cluster_add! calls at :300, deepcopies at :336 */
     int64_t *dbg_cols;      /* analysis only (scripts/column_stats.py): [step][k] distinct columns of particle[:, :, k] before the ESS test */
+    int64_t *dbg_steps;     /* analysis / work-counter checks: [step][k][8], see pmdi_oracle_debug_steps */
+    uint8_t *dbg_mark;      /* [pool+1] scratch of the above */
     /* scratch */
     int64_t *partstar, *tmp_i64, *idmap;
     double  *tmp_d;
@@ -446,7 +448,7 @@ void pmdi_oracle_destroy(pmdi_oracle *h)
     free(h->fprob_dict); free(h->fprob_done); free(h->fprob); free(h->logprob);
     free(h->logweight); free(h->cluster_update); free(h->counts); free(h->sstar_id);
     free(h->sstar); free(h->maxid); free(h->partstar); free(h->tmp_i64); free(h->idmap);
-    free(h->tmp_d); free(h->tmp_u8);
+    free(h->tmp_d); free(h->tmp_u8); free(h->dbg_mark);
     free(h);
 }
 
@@ -530,6 +532,29 @@ static double now_seconds(void)
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* distinct columns particle[:, p, k] over the particles: sorted insertion of the columns' 64-bit hashes (analysis only) */
+static int64_t count_distinct_columns(pmdi_oracle *h, int k)
+{
+    const int N = h->N, P = h->P;
+    const int64_t *particle = h->particle + (int64_t)k * P * N;
+    uint64_t *hs = (uint64_t *)h->tmp_d;          /* P doubles = P hashes */
+    for (int p = 0; p < P; ++p) {
+        uint64_t x = 1469598103934665603ull;
+        for (int nn = 0; nn < N; ++nn) { x ^= (uint64_t)particle[(int64_t)p * N + nn]; x *= 1099511628211ull; x ^= x >> 29; }
+        hs[p] = x;
+    }
+    int64_t nc = 0;
+    for (int p = 0; p < P; ++p) {                 /* insertion into the sorted distinct prefix: fine for the small counts of interest */
+        int64_t lo = 0, hi = nc;
+        while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (hs[mid] < hs[p]) lo = mid + 1; else hi = mid; }
+        if (lo < nc && hs[lo] == hs[p]) continue;
+        uint64_t v = hs[p];
+        memmove(hs + lo + 1, hs + lo, (size_t)(nc - lo) * sizeof(uint64_t));
+        hs[lo] = v; nc += 1;
+    }
+    return nc;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -620,11 +645,18 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                 st.n_operations += 1;                  /* src/__pmdi.jl:187 */
             }
 
+            int64_t *dbg = h->dbg_steps ? h->dbg_steps + ((pos - (n1 - 1)) * K + k) * 8 : NULL;
+            if (dbg) { memset(dbg, 0, 8 * sizeof(int64_t)); dbg[6] = maxid; }
             int64_t curr_id = 0;                      /* :222 */
             for (int p = 0; p < P; ++p) {             /* :223 */
                 int64_t id = particle_id[p];
                 const int64_t *part_p = particle + (int64_t)p * N;
                 double *dict = h->fprob_dict + (id - 1) * (N + 1);
+                if (dbg && !h->fprob_done[id]) {      /* a class leader: the entries of logprob it reads at :232 */
+                    dbg[0] += 1;
+                    for (int nn = 0; nn < N; ++nn)
+                        if (!h->dbg_mark[part_p[nn]]) { h->dbg_mark[part_p[nn]] = 1; dbg[1] += 1; }
+                }
                 if (h->fprob_done[id]) {              /* :225-229 */
                     for (int nn = 0; nn < N; ++nn) fprob[nn] = dict[nn];
                     logweight[p] += dict[N];
@@ -671,6 +703,14 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                 }
             }
 
+            if (dbg) {
+                /* clear the marks through the leaders (lowest particle of every class at the start of the step); fprob_done
+                 * is indexed by the class ids of the step's start, which particle_id no longer holds: walk the table instead */
+                for (int64_t e = 0; e < (int64_t)P * N; ++e) h->dbg_mark[particle[e]] = 0;
+                int un = 1;
+                for (int p = 1; p < P; ++p) if (ss[p] != ss[0] || sstar_id[p] != sstar_id[0]) { un = 0; break; }
+                dbg[7] = un;
+            }
             /* copy-on-write update: src/pmdi.jl:275-310 */
             int64_t max_k = maxid;
             if (h->faithful_cost) {
@@ -698,6 +738,7 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                 }
                 cl_add(pl, id, i, flags[k]);          /* :300 */
                 h->last_updates[k] += 1;
+                if (dbg) { dbg[2] += 1; dbg[3] += (id != c); }
                 if (id != c) {                        /* :301-308 */
                     for (int part = 0; part < P; ++part) {
                         int64_t s_id = ss[part];
@@ -725,28 +766,10 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                 }
         }
 
-        if (h->dbg_cols) {
-            /* distinct columns particle[:, p, k] over the particles: sort the columns' 64-bit hashes (analysis only) */
-            for (int k = 0; k < K; ++k) {
-                const int64_t *particle = h->particle + (int64_t)k * P * N;
-                uint64_t *hs = (uint64_t *)h->tmp_d;          /* P doubles = P hashes */
-                for (int p = 0; p < P; ++p) {
-                    uint64_t x = 1469598103934665603ull;
-                    for (int nn = 0; nn < N; ++nn) { x ^= (uint64_t)particle[(int64_t)p * N + nn]; x *= 1099511628211ull; x ^= x >> 29; }
-                    hs[p] = x;
-                }
-                int64_t nc = 0;
-                for (int p = 0; p < P; ++p) {                 /* insertion into the sorted distinct prefix: fine for the small counts of interest */
-                    int64_t lo = 0, hi = nc;
-                    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (hs[mid] < hs[p]) lo = mid + 1; else hi = mid; }
-                    if (lo < nc && hs[lo] == hs[p]) continue;
-                    uint64_t v = hs[p];
-                    memmove(hs + lo + 1, hs + lo, (size_t)(nc - lo) * sizeof(uint64_t));
-                    hs[lo] = v; nc += 1;
-                }
-                h->dbg_cols[(pos - (n1 - 1)) * K + k] = nc;
-            }
-        }
+        if (h->dbg_cols)
+            for (int k = 0; k < K; ++k) h->dbg_cols[(pos - (n1 - 1)) * K + k] = count_distinct_columns(h, k);
+        if (h->dbg_steps)
+            for (int k = 0; k < K; ++k) h->dbg_steps[((pos - (n1 - 1)) * K + k) * 8 + 4] = count_distinct_columns(h, k);
         double ess = pmdi_oracle_calc_ess(logweight, P);
         int resampled = 0;
         if (ess <= 0.5 * (double)P) {                 /* :317 */
@@ -801,6 +824,9 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                 h->maxid[k] = next;
             }
         }
+        if (h->dbg_steps)   /* distinct columns after the (possible) resampling: what the next step starts from */
+            for (int k = 0; k < K; ++k)
+                h->dbg_steps[((pos - (n1 - 1)) * K + k) * 8 + 5] = resampled ? count_distinct_columns(h, k) : h->dbg_steps[((pos - (n1 - 1)) * K + k) * 8 + 4];
         if (trace) {
             double *tr = trace + (pos - (n1 - 1)) * (2 + 2 * K);
             tr[0] = ess; tr[1] = (double)resampled;
@@ -870,6 +896,22 @@ int pmdi_oracle_feature_select(pmdi_oracle *h, int64_t iter, const int64_t *s_tr
 }
 
 void pmdi_oracle_debug_columns(pmdi_oracle *h, int64_t *buf) { h->dbg_cols = buf; }
+
+/* Per (swept observation, dataset) record of the next sweeps, buf[step][k][8] (NULL switches it off):
+ *   0 particle classes at the start of the step (CDFs formed, :231-248)   1 distinct clusters those classes' leaders read at :232
+ *   2 distinct chosen clusters (cluster_add! calls, :300)                 3 of which cloned (:292-298)
+ *   4 distinct columns of particle[:, :, k] before the ESS test           5 ... after the resampling of this observation, if any
+ *   6 maximum(particle_k) at the start of the step                        7 1 if every particle drew the same label and cluster
+ * What the device's work counters (clusters evaluated, columns met by resampling events, copy-on-write splits) are checked against. */
+int pmdi_oracle_debug_steps(pmdi_oracle *h, int64_t *buf)
+{
+    h->dbg_steps = buf;
+    if (buf && !h->dbg_mark) {
+        h->dbg_mark = (uint8_t *)calloc((size_t)h->pool_cap + 2, 1);
+        if (!h->dbg_mark) { h->dbg_steps = NULL; return -1; }
+    }
+    return 0;
+}
 
 int pmdi_oracle_export(const pmdi_oracle *h, int64_t *particle, int64_t *counts,
                        int64_t *cluster_n, int64_t *max_id)

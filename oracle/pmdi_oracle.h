@@ -96,6 +96,8 @@ int pmdi_oracle_export(const pmdi_oracle *h, int64_t *particle, int64_t *counts,
 /* Per dataset, last sweep: distinct clusters updated (cluster_add! at src/pmdi.jl:300) and clusters moved down by the
  * renumbering of resampling events (deepcopy at :336). */
 void pmdi_oracle_work(const pmdi_oracle *h, int64_t *updates, int64_t *moved);
+/* per-step analysis record [step][k][8] of the next sweeps (see pmdi_oracle.c); NULL = off */
+int pmdi_oracle_debug_steps(pmdi_oracle *h, int64_t *buf);
 
 /* --- cluster plugin protocol on stand-alone clusters (unit tests) -------- */
 typedef struct pmdi_oracle_cluster pmdi_oracle_cluster;

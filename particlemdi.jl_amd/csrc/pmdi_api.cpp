@@ -147,7 +147,16 @@ struct pmdi_handle {
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
     DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
     int ksplit = 0;
+    int ksplit_batch = 0;        // split mode: chain slots per launch when n_chains * K workgroups are not resident at once (0 = one launch)
     bool have_order = false;
+    // argument blocks travel through a ring of pinned host slots: the stream-ordered copy is then asynchronous for the host too
+    static constexpr int RING = 64;
+    SweepArgs *ring = nullptr;
+    hipEvent_t ring_ev[RING] = {};
+    bool ring_used[RING] = {};
+    int ring_head = 0;
+    int err_keep = 0;            // set by the device-resident driver around its sweeps (pmdi_gibbs_step)
+    int children = 0;            // live pmdi_gibbs / cluster-batch objects: pmdi_destroy refuses while > 0
     // feature selection
     DevBuf d_traj, d_lm, d_firstpos, d_fnull, d_fflags, d_fprob;
     bool swept = false;
@@ -165,6 +174,7 @@ struct pmdi_cluster_batch {
 // Device-resident Gibbs state of every chain of a handle (pmdi_gibbs_* entry points)
 struct pmdi_gibbs {
     pmdi_handle *h = nullptr;
+    int device = 0;                      // (cached: destroy must not have to look at the handle)
     GibbsArgs ga{};
     int *s_next = nullptr;               // the sweep's output; exchanged with ga.s after every sweep
     unsigned char *flags = nullptr;      // [chain][sumD] featureFlag
@@ -221,6 +231,42 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
 }
 
+// next pinned staging slot of the handle's ring (waits -- normally not at all -- for the copy that last used it)
+SweepArgs *next_slot(pmdi_handle *h, hipStream_t st_of_copy, int *idx)
+{
+    (void)st_of_copy;
+    if (!h->ring) { *idx = -1; return nullptr; }
+    const int i = h->ring_head;
+    h->ring_head = (i + 1) % pmdi_handle::RING;
+    if (h->ring_used[i]) (void)hipEventSynchronize(h->ring_ev[i]);
+    *idx = i;
+    return h->ring + i;
+}
+
+hipError_t launch_one(pmdi_handle *h, const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t st)
+{
+    int idx;
+    SweepArgs *slot = next_slot(h, st, &idx);
+    hipError_t e = pmdi_launch_sweep(a, d_args, n_chains, T, st, slot);
+    if (e == hipSuccess && idx >= 0) { e = hipEventRecord(h->ring_ev[idx], st); h->ring_used[idx] = true; }
+    return e;
+}
+
+// split mode: all chain slots in one launch when their K workgroups each are resident at once, else in residency-sized batches
+// one after the other (a chain whose partners straddle the residency limit would spin until some other chain's whole sweep ends)
+hipError_t launch_maybe_batched(pmdi_handle *h, const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t st)
+{
+    if (!a.ksplit || h->ksplit_batch <= 0 || n_chains <= h->ksplit_batch) return launch_one(h, a, d_args, n_chains, T, st);
+    for (int b0 = 0; b0 < n_chains; b0 += h->ksplit_batch) {
+        SweepArgs ab = a;
+        ab.n_slots = n_chains; ab.slot_base = b0;
+        const int nb = (n_chains - b0 < h->ksplit_batch) ? n_chains - b0 : h->ksplit_batch;
+        hipError_t e = launch_one(h, ab, d_args, nb, T, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // One sweep of all chains on stream `st`: a single launch, or (automatic width) the heavy chains in
 // wide workgroups on `st` and the light ones in 256-thread workgroups on the handle's second stream,
 // forked from and joined back into `st`.  Then the launch order and groups of the next sweep.
@@ -228,13 +274,14 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
 {
     const int C = h->cfg.n_chains;
     hipError_t e;
+    a.err_keep = h->err_keep;
     if (h->ksplit) {       // arrival counters of the hand-offs; the K workgroups of a chain ADD their counters into stats
         HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, st));
         HIP_TRY(hipMemsetAsync(a.stats, 0, (size_t)C * 64, st));
-        HIP_TRY(hipMemsetAsync(a.err, 0, (size_t)C * 4, st));
+        if (!h->err_keep) HIP_TRY(hipMemsetAsync(a.err, 0, (size_t)C * 4, st));
     }
     if (!h->split) {
-        e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, st);
+        e = launch_maybe_batched(h, a, (SweepArgs *)h->d_args.p, C, h->T, st);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch: %s", hipGetErrorString(e));
     } else {
         HIP_TRY(hipEventRecord(h->ev_fork, st));
@@ -252,7 +299,7 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
             // take 550 ms).  So its workgroups count themselves in on entry and the other launches wait for that count.
             const bool gate = h->start_sig != nullptr && !h->ksplit;
             if (gate) av.start_sig = h->start_sig;      // (zero here: reset on `st` behind the previous sweep's join, below)
-            e = pmdi_launch_sweep(av, (SweepArgs *)h->d_args3.p, vh, h->T, h->stream3);
+            e = launch_one(h, av, (SweepArgs *)h->d_args3.p, vh, h->T, h->stream3);
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (heaviest chains): %s", hipGetErrorString(e));
             HIP_TRY(hipEventRecord(h->ev_join3, h->stream3));
             if (gate) {
@@ -263,20 +310,20 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
             }
         }
         a.rank_lo = vh; a.rank_hi = C;
-        e = pmdi_launch_sweep(a, (SweepArgs *)h->d_args.p, C, h->T, st);
+        e = launch_maybe_batched(h, a, (SweepArgs *)h->d_args.p, C, h->T, st);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (heavy group): %s", hipGetErrorString(e));
-        if (vh > 0) {
-            HIP_TRY(hipStreamWaitEvent(st, h->ev_join3, 0));
-            if (h->start_sig && !h->ksplit) HIP_TRY(hipStreamWriteValue32(st, h->start_sig, 0, 0));   // re-arm the start gate
-        }
+        if (vh > 0) HIP_TRY(hipStreamWaitEvent(st, h->ev_join3, 0));
         SweepArgs al = a;
         al.group_sel = 0; al.rank_lo = 0; al.rank_hi = C;
         al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds; al.col_lds = h->l_col_lds;
         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        e = pmdi_launch_sweep(al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
+        e = launch_maybe_batched(h, al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (light group): %s", hipGetErrorString(e));
         HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
         HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
+        // re-arm the start gate only here: `st` has now joined BOTH gated consumers (its own wait and stream2's), so neither can
+        // still be waiting for the value that is being reset
+        if (vh > 0 && h->start_sig && !h->ksplit) HIP_TRY(hipStreamWriteValue32(st, h->start_sig, 0, 0));
     }
     if (C > 1 || h->split) {
         const long long steps = (a.n - a.n1 + 1) * (long long)a.K;
@@ -298,8 +345,13 @@ int pmdi_abi_version(void) { return PMDI_ABI_VERSION; }
 int pmdi_destroy(pmdi_handle *h)
 {
     if (!h) return PMDI_OK;
+    if (h->children > 0)
+        return fail(PMDI_E_STATE, "pmdi_destroy: %d object(s) created from this handle (pmdi_gibbs_create / pmdi_clusters_new) are still alive", h->children);
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < pmdi_handle::RING; ++i) if (h->ring_ev[i]) (void)hipEventDestroy(h->ring_ev[i]);
+    if (h->ring) (void)hipHostFree(h->ring);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
                       &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
@@ -435,17 +487,17 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     {
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
         if (2 * N > PMDI_ITEM_CAP) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));
-        h->two_per_cu = env_int("PMDI_TWO_PER_CU", 1);
         // K > 1: one workgroup per (chain, dataset), meeting once per swept observation (pmdi_sweep.hip): 2.2x shorter sweeps per
         // chain, but the partners repeat the per-observation serial work (weights, ESS, resampling indices), so when the chains alone
-        // can fill the GPU twice over the single-workgroup form has the higher aggregate throughput.  Default: split while
-        // n_chains * K workgroups fit the device at once (two 512-thread workgroups per CU); PMDI_KSPLIT=0/1 forces either form.
-        // The history-permuting __pmdi mode keeps the single-workgroup form (its ancestor log is per chain).
-        {
-            const int slots = 2 * prop.multiProcessorCount;
-            const int dflt = ((long long)cfg->n_chains * K <= slots) ? 1 : 0;
-            h->ksplit = (K > 1 && cfg->q2_mode == 0 && (long long)K * n < (1LL << 27) && env_int("PMDI_KSPLIT", dflt) != 0) ? 1 : 0;
-        }
+        // can fill the GPU the single-workgroup form has the higher aggregate throughput.  Default: split while every workgroup of
+        // the split launch is RESIDENT at once -- decided below, after the LDS layout and the register-capped / uncapped build are
+        // known, from the occupancy of the kernel that will actually run (a chain whose K workgroups straddle the residency limit
+        // would spin in its hand-off until some other chain's whole sweep has ended).  PMDI_KSPLIT=0/1 forces either form (a forced
+        // split launch that is not resident at once goes out in residency-sized batches).  The history-permuting __pmdi mode
+        // (q2_mode = 1) always keeps the single-workgroup form: its ancestor log is per chain.
+        const bool ks_ok = K > 1 && cfg->q2_mode == 0 && (long long)K * n < (1LL << 27);
+        const int ks_env = env_int("PMDI_KSPLIT", -1);
+        h->ksplit = (ks_ok && ks_env != 0) ? 1 : 0;      // tentative: the layout below is the split form's
         h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
         // per workgroup width: LDS term buffer (at least P doubles for the resampling weights, the
         // per-wave CDF exchange areas, a few rows of 2*D+1) and which per-particle tables fit LDS
@@ -487,11 +539,33 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 return fail(PMDI_E_ARG, "configuration needs %zu bytes of LDS (> 160 KiB)", pmdi_sweep_lds_bytes(a, T));
             return 0;
         };
-        if ((rc = configure(h->T, h->terms_cap, h->pid_lds, h->pp_lds, h->col_lds))) return bail(rc);
-        {   // one chain per CU anyway: the 256-register build (no spills) instead of the register-capped one
+        auto configure_wide = [&]() -> int {
+            h->two_per_cu = env_int("PMDI_TWO_PER_CU", 1);
+            const int r = configure(h->T, h->terms_cap, h->pid_lds, h->pp_lds, h->col_lds);
+            if (r) return r;
+            // one chain per CU anyway: the 256-register build (no spills) instead of the register-capped one
             SweepArgs a;
             fill_sweep_common(h, a);
             if (!getenv("PMDI_TWO_PER_CU") && pmdi_sweep_lds_bytes(a, h->T) > 80 * 1024 - 256) h->two_per_cu = 0;
+            return 0;
+        };
+        if ((rc = configure_wide())) return bail(rc);
+        if (h->ksplit) {
+            SweepArgs a;
+            fill_sweep_common(h, a);
+            int blocks = 0;
+            if (pmdi_sweep_blocks_per_cu(a, h->T, &blocks) != hipSuccess || blocks < 1) blocks = 1;
+            const long long capacity = (long long)blocks * prop.multiProcessorCount;
+            const long long grid = ((long long)(cfg->n_chains + 7) / 8) * 8 * K;       // chain slots are dealt in groups of eight
+            if (grid > capacity) {
+                if (ks_env < 0) {                        // default: the single-workgroup form (and its own LDS layout)
+                    h->ksplit = 0;
+                    if ((rc = configure_wide())) return bail(rc);
+                } else {                                 // forced: whole groups of eight chain slots that are resident together
+                    long long b = capacity / (8LL * K) * 8;
+                    h->ksplit_batch = (int)(b < 8 ? 8 : b);
+                }
+            }
         }
         // automatic width: split the chains of a sweep into a heavy and a light launch
         h->split = cfg->block_threads == 0 && h->T > 256 && env_int("PMDI_SPLIT", 1) != 0;
@@ -534,6 +608,18 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
         return bail(rc);
+    {   // pinned staging ring of the argument blocks (asynchronous launches); without it the copies fall back to pageable memory
+        void *ring = nullptr;
+        if (hipHostMalloc(&ring, sizeof(SweepArgs) * pmdi_handle::RING, hipHostMallocDefault) == hipSuccess) {
+            h->ring = (SweepArgs *)ring;
+            for (int i = 0; i < pmdi_handle::RING; ++i)
+                if (hipEventCreateWithFlags(&h->ring_ev[i], hipEventDisableTiming) != hipSuccess) {
+                    for (int j = 0; j < i; ++j) { (void)hipEventDestroy(h->ring_ev[j]); h->ring_ev[j] = nullptr; }
+                    (void)hipHostFree(ring); h->ring = nullptr;
+                    break;
+                }
+        }
+    }
     if (h->ksplit && ((rc = h->d_xcnt.ensure((size_t)C * 32 * 4)) || (rc = h->d_xinc.ensure((size_t)C * 2 * K * P * 8)) ||
                       (rc = h->d_xlab.ensure((size_t)C * 2 * K * P * 4)) || (rc = h->d_xhdr.ensure((size_t)C * 2 * K * 16))))
         return bail(rc);
@@ -828,9 +914,10 @@ int pmdi_clusters_new(pmdi_handle *h, int32_t k, int32_t B, pmdi_cluster_batch *
     if (!cb) return fail(PMDI_E_MEMORY, "out of host memory");
     cb->h = h; cb->k = k; cb->B = B;
     cb->d = h->ds[k];
+    h->children += 1;
     cb->d.stride = layout_arena(cb->d, h->cfg.N, h->cfg.P, B, 0, false);
     hipError_t e = hipMalloc(&cb->arena, cb->d.stride);
-    if (e != hipSuccess) { delete cb; return fail(PMDI_E_MEMORY, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { h->children -= 1; delete cb; return fail(PMDI_E_MEMORY, "hipMalloc: %s", hipGetErrorString(e)); }
     cb->d.arena = (char *)cb->arena;
     (void)hipMemset(cb->arena, 0, cb->d.stride);
     if (cb->d.kind == K_GAUSSIAN) {     // GaussianCluster(dataFile): mu=Sigma=0, lambda=1, beta=0.5 (gaussian_cluster.jl:17-21)
@@ -849,6 +936,7 @@ int pmdi_clusters_free(pmdi_cluster_batch *cb)
     (void)hipSetDevice(cb->h->cfg.device);
     if (cb->arena) (void)hipFree(cb->arena);
     cb->d_rows.release(); cb->d_flags.release(); cb->d_out.release();
+    if (cb->h->children > 0) cb->h->children -= 1;
     delete cb;
     return PMDI_OK;
 }
@@ -991,9 +1079,10 @@ extern "C" {
 int pmdi_gibbs_destroy(pmdi_gibbs *g)
 {
     if (!g) return PMDI_OK;
-    (void)hipSetDevice(g->h->cfg.device);
+    (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
     for (void *p : g->owned) (void)hipFree(p);
+    if (g->h && g->h->children > 0) g->h->children -= 1;      // (the handle outlives its children: pmdi_destroy refuses otherwise)
     delete g;
     return PMDI_OK;
 }
@@ -1010,7 +1099,8 @@ int pmdi_gibbs_create(pmdi_handle *h, double rho, int32_t feature_select, pmdi_g
     HIP_TRY(hipSetDevice(h->cfg.device));
     pmdi_gibbs *g = new (std::nothrow) pmdi_gibbs();
     if (!g) return fail(PMDI_E_MEMORY, "out of host memory");
-    g->h = h; g->n1 = n1; g->feature_select = feature_select ? 1 : 0;
+    g->h = h; g->device = h->cfg.device; g->n1 = n1; g->feature_select = feature_select ? 1 : 0;
+    h->children += 1;
     GibbsArgs &a = g->ga;
     a.K = K; a.N = N; a.npairs = h->npairs; a.n_chains = C; a.n = n; a.iter = 0; a.seed = h->cfg.seed;
     int rc = 0;
@@ -1049,7 +1139,8 @@ int pmdi_gibbs_create(pmdi_handle *h, double rho, int32_t feature_select, pmdi_g
                             host_uniform01(h->cfg.seed + (unsigned long long)c, 0, 0, (unsigned)k, (unsigned)q, SITE_INIT_FLAGS) < 0.5 ? 1 : 0;
         if (hipMemcpy(g->flags, fl.data(), fl.size(), hipMemcpyHostToDevice) != hipSuccess) { pmdi_gibbs_destroy(g); return fail(PMDI_E_DEVICE, "memcpy failed"); }
     }
-    if (hipMemset(g->err, 0, (size_t)C * 4) != hipSuccess || hipMemset(g->stats, 0, (size_t)C * 64) != hipSuccess) {
+    if (hipMemset(g->err, 0, (size_t)C * 4) != hipSuccess || hipMemset(g->stats, 0, (size_t)C * 64) != hipSuccess ||
+        hipMemset(g->s_next, 0, (size_t)C * K * n * 4) != hipSuccess) {
         pmdi_gibbs_destroy(g);
         return fail(PMDI_E_DEVICE, "memset failed");
     }
@@ -1078,8 +1169,12 @@ int pmdi_gibbs_step(pmdi_gibbs *g, int32_t what, void *stream)
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "hypers launch: %s", hipGetErrorString(e));
         return PMDI_OK;
     case PMDI_STEP_SWEEP: {
+        // the first error of a chain sticks (a later, successful sweep does not reset it): pmdi_gibbs_results reports it,
+        // pmdi_gibbs_set of that chain clears it.  A failed chain keeps its allocations (the kernel copies s_in to s_out).
+        h->err_keep = 1;
         const int rc = pmdi_sweep_device(h, g->iter, a.s, a.order, g->n1, a.Pi, a.logphi, g->flags, g->iter == 1 ? 0.0 : 1.0,
                                          g->s_next, g->lw, g->pstar, (int64_t *)g->stats, g->err, stream);
+        h->err_keep = 0;
         if (rc) return rc;
         std::swap(g->ga.s, g->s_next);               // s = sstar[p_star, :, :] (src/pmdi.jl:373)
         return PMDI_OK;
@@ -1210,6 +1305,7 @@ int pmdi_gibbs_set(pmdi_gibbs *g, int32_t chain, const double *M, const double *
         HIP_TRY(hipMemcpy(a.order + (size_t)chain * n, t.data(), t.size() * 4, hipMemcpyHostToDevice));
     }
     if (feature_flag) HIP_TRY(hipMemcpy(g->flags + (size_t)chain * h->sumD, feature_flag, (size_t)h->sumD, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(g->err + chain, 0, 4));                 // a chain given a new state starts without its sticky error
     return PMDI_OK;
 }
 

@@ -119,7 +119,14 @@ int pmdi_comm_init_all(int32_t n_devices, const int32_t *devices, pmdi_comm **ou
     NCCL_TRY(g_rccl.CommInitAll(comms.data(), n_devices, devs.data()));
     for (int i = 0; i < n_devices; ++i) {
         pmdi_comm *c = new (std::nothrow) pmdi_comm();
-        if (!c) return pmdi_set_error(PMDI_E_MEMORY, "out of host memory");
+        if (!c) {
+            // nothing half-made is left behind: the wrappers built so far (they own their communicators) and the
+            // communicators that have no wrapper yet
+            for (int j = 0; j < i; ++j) { (void)pmdi_comm_destroy(out[j]); out[j] = nullptr; }
+            for (int j = i; j < n_devices; ++j)
+                if (comms[j] && g_rccl.CommDestroy) { (void)hipSetDevice(devs[j]); (void)g_rccl.CommDestroy(comms[j]); }
+            return pmdi_set_error(PMDI_E_MEMORY, "out of host memory");
+        }
         c->comm = comms[i]; c->device = devs[i]; c->rank = i; c->n_ranks = n_devices;
         out[i] = c;
     }

@@ -46,14 +46,13 @@ template <class Tp> __device__ __forceinline__ Tp *gen(PMDI_GLOBAL Tp *p) { retu
 __device__ __forceinline__ double2 ld2(const PMDI_GLOBAL dbl2v *p, size_t i) { const dbl2v v = p[i]; return make_double2(v.x, v.y); }
 __device__ __forceinline__ void st2(PMDI_GLOBAL dbl2v *p, size_t i, double2 v) { dbl2v w; w.x = v.x; w.y = v.y; p[i] = w; }
 
-#if defined(PMDI_EXP_LAZY_KS) && defined(PMDI_SWEEP_TU)
-// EXPERIMENT (default off; the default build is instruction-identical without it -- checked by diffing the assembly).
-// The 22 pointers of a KS are wave-uniform, but the step loop cannot keep them in SGPRs: make_ks() at the top of every step
-// computes them, the register allocator parks them in VGPRs and spills those -- 22 scratch stores per lane and step in the
-// 256-register build (hipcc -gline-tables-only -S: every scratch_store of the step loop sits on make_ks' lines), i.e. ~22 KB
-// of the ~50 KB of spill write-back per chain and step (profiles/README.md), and a scratch reload in front of every phase.
-// Here a field is a (dataset, chain) pair and the address is rebuilt where it is used, from scalar loads of the argument
-// block (the asm keeps the loads from being hoisted back out of the step loop).
+#if defined(PMDI_SWEEP_TU)
+// The 22 array pointers of a (chain, dataset) are wave-uniform, but the step loop cannot keep them in SGPRs: computed at the top
+// of every step they were parked in VGPRs and spilled -- 22 scratch stores per lane and step in the 256-register build, about half
+// of the spill write-back per chain and step, and a scratch reload in front of every phase (profiles/README.md, round 2).  Here a
+// field is a (dataset, chain) pair and the address is rebuilt where it is used, from scalar loads of the argument block (the asm
+// keeps the loads from being hoisted back out of the step loop).  Round 3 A/B on the GPU, same box back to back: HL 459.9 ->
+// 495.6 iterations/s, parity suite equal; kernel body 36 -> 5 scratch stores.
 typedef const __attribute__((address_space(4))) DsetDev *cdsptr;   // the argument block through the constant address space: s_load
 __device__ __forceinline__ cdsptr opaque_ds(const DsetDev *d)
 {

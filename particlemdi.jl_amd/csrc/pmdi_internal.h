@@ -117,6 +117,8 @@ struct SweepArgs {
                                 // wait for the heaviest chains' workgroups to have been placed (a whole CU each) before they start
     int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
     int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
+    int slot_base;              // split mode launched in residency-sized batches: first chain slot of this launch
+    int err_keep;               // 1: a successful sweep leaves err[chain] as it is (device-resident chains: the first error sticks)
 };
 
 struct ClusterBatchArgs {
@@ -173,7 +175,10 @@ hipError_t pmdi_launch_align(const GibbsArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_pack_samples(const int *s, unsigned char *out, long long count, hipStream_t stream);
 
 size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T);
-hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t stream);
+// `staging`: a pinned host slot the argument block is copied through (truly asynchronous), or null (pageable copy: host-synchronous)
+hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t stream, SweepArgs *staging = nullptr);
+// workgroups of the sweep kernel build (T threads, the argument block's LDS layout) that one CU holds at once
+hipError_t pmdi_sweep_blocks_per_cu(const SweepArgs &a, int T, int *blocks);
 hipError_t pmdi_launch_cluster_add(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logprob(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_t stream);

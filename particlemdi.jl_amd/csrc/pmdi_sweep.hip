@@ -19,7 +19,7 @@
 //     falls back to per-id tables in global memory -- same results, slower.
 //
 // Reference lines are cited as file:line relative to /root/reference.
-#define PMDI_SWEEP_TU 1     // (the default-off KS experiment of pmdi_device.h applies to this file only)
+#define PMDI_SWEEP_TU 1     // (this file gets the KS whose array addresses are rebuilt from the argument block where they are used: pmdi_device.h)
 #include "pmdi_device.h"
 
 using namespace pmdi_dev;
@@ -142,13 +142,11 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     c.knflag = take(PMDI_KMAX_I * 4);
     c.khint = take(PMDI_KMAX_I * 4);
     c.kncol = take(PMDI_KMAX_I * 4);
-#ifndef PMDI_EXP_LEAF_ALIAS
     c.leaf_i1 = take(64 * 4);
     c.leaf_n = take(64 * 4);
     c.leaf_tot = take(64 * 8);
     c.leaf_carry = take(64 * 8);
     c.leaf_prog = take(256);
-#endif
     c.dl_slot = take((size_t)PMDI_DL_LDS * 4);
     c.h1k = take((size_t)PMDI_HT_SIZE * 4);
     c.h1a = take((size_t)PMDI_HT_SIZE * 4);
@@ -165,9 +163,6 @@ __host__ __device__ inline void carve_lds(const SweepArgs &a, Carve &c)
     const int KL = a.ksplit ? 1 : a.K;                       // datasets this workgroup sweeps
     c.lpl = take(icap * 8);
     c.cdf = take((2 * icap + 4) * 8);                        // rows of N + 2: CDF, log-increment, one-hot label
-#ifdef PMDI_EXP_LEAF_ALIAS                                   // (experiment: the CDF rows are idle during a resampling event)
-    c.leaf_i1 = c.cdf; c.leaf_n = c.cdf + 256; c.leaf_tot = c.cdf + 512; c.leaf_carry = c.cdf + 1024; c.leaf_prog = c.cdf + 1536;
-#endif
     c.need = take(icap * 4);
     c.need_slot = take(icap * 4);
     c.item_id = take(icap * 4);
@@ -242,8 +237,7 @@ __device__ __forceinline__ Dual<Tp> dual(bool lds, __attribute__((address_space(
 {
     return Dual<Tp>{l, g, lds};
 }
-#if defined(PMDI_EXP_LAZY_KS)
-// (experiment, default off: pmdi_device.h)  Dual whose global side is rebuilt from the argument block where it is used
+// Dual whose global side is rebuilt from the argument block where it is used (pmdi_device.h, LazyArr)
 template <class Tp, size_t DsetDev::*OFF>
 struct DualL {
     __attribute__((address_space(3))) Tp *l;
@@ -265,7 +259,6 @@ __device__ __forceinline__ DualL<Tp, OFF> dual(bool lds, __attribute__((address_
 {
     return DualL<Tp, OFF>{l, g, 0, lds};
 }
-#endif
 
 struct ClsList {
     lint l_lead, l_val;
@@ -318,7 +311,7 @@ __device__ __forceinline__ int rebuild_classes(const DualT &pidk, const ClsList 
     /* split mode: the K datasets of a chain are swept by K cooperating workgroups (blocks b, b+8, ... share a chain's \
        XCD under round-robin placement: speed only, the hand-off is placement-independent) */  \
     const int Kf = a.K;                                                                        \
-    const int bslot = a.ksplit ? (int)((blockIdx.x / (8u * (unsigned)Kf)) * 8u + (blockIdx.x & 7u)) : (int)blockIdx.x; \
+    const int bslot = a.ksplit ? a.slot_base + (int)((blockIdx.x / (8u * (unsigned)Kf)) * 8u + (blockIdx.x & 7u)) : (int)blockIdx.x; \
     const int kd0 = a.ksplit ? (int)((blockIdx.x >> 3) % (unsigned)Kf) : 0;                    \
     const int chain = bslot < a.n_slots ? (a.chain_order ? a.chain_order[bslot] : bslot) : 0;  \
     const int K = ((K1_) || a.ksplit) ? 1 : a.K, N = a.N, P = a.P, cap = a.cap;                \
@@ -379,9 +372,7 @@ __device__ __forceinline__ void build_sh(const SweepArgs &a, unsigned char *smem
 // hoisted across the whole sweep loop and spill the hot path's registers).  Each one rebuilds
 // its view of the arguments and of the LDS table.
 
-// (the leaf decomposition of the resampling cumsum, as a macro: built once per sweep in the prefix -- or, in the default-off
-// experiment PMDI_EXP_LEAF_ALIAS, at every resampling event into tables that share the CDF rows' LDS: 1.8 KB less, which is
-// what keeps the class ids and the column indices from both fitting the two-per-CU budget at cfg2)
+// (the leaf decomposition of the resampling cumsum, as a macro: built once per sweep in the prefix)
 #define PMDI_BUILD_LEAF_PROGRAM()                                                                       \
     do {                                                                                                \
             int nl = 0, np = 0, sp = 0;                                                                 \
@@ -421,9 +412,7 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
         // leaf decomposition of Julia's accumulate_pairwise! over [1, P) and its recursion as a
         // post-order program (0 leaf, 3 descend left, 1 left done -> right, 2 node done), used by
         // the resampling cumsum.  More than 64 leaves (P > ~4096): the serial form is used.
-#ifndef PMDI_EXP_LEAF_ALIAS
         PMDI_BUILD_LEAF_PROGRAM();
-#endif
     }
     __syncthreads();
     // ---- reset (src/pmdi.jl:165-171) and known prefix (src/pmdi.jl:188-207) ----
@@ -982,9 +971,6 @@ __device__ PMDI_COLD_RESAMPLE void sweep_resample(const SweepArgs *__restrict__ 
             const double u01 = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
             const double usl = uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
             double *wb = gen(sh.term);
-#ifdef PMDI_EXP_LEAF_ALIAS
-            if (tid == 0) PMDI_BUILD_LEAF_PROGRAM();
-#endif
             for (int p = tid; p < P; p += T) wb[p] = exp(sh.lw[p] - mx);
             __syncthreads();
             PHR(0);   // weights
@@ -1349,7 +1335,7 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
                 st[ST_NOPS] = sh.stat[0]; st[ST_NRESAMPLE] = sh.stat[1]; st[ST_NCLONES] = sh.stat[2];
                 st[ST_MAXID] = sh.stat[3]; st[ST_SUMCLASSES] = sh.stat[4];
                 st[5] = sh.stat[5]; st[6] = sh.stat[6]; st[7] = sh.stat[7];
-                a.err[chain] = 0;
+                if (!a.err_keep) a.err[chain] = 0;
             } else {
                 // the K workgroups of the chain add their datasets' counters (the host zeroed stats and err before the launch)
                 if (kd0 == 0) { a.pstar[chain] = pstar; st[ST_NRESAMPLE] = sh.stat[1]; }
@@ -1499,88 +1485,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 PH(2); FRESH_LANE_IDS();
                 sweep_logprob_all<T>(ap, k, maxid);
             }
-#ifdef PMDI_EXP_WAVE_SUM
-            // EXPERIMENT (default off): D <= 64 -- one wave per needed cluster, a lane per feature; the per-feature terms stay in
-            // registers and the wave adds them in feature order through v_readlane (same terms, same order as the LDS-staged form:
-            // bit-identical), two clusters per wave at a time so that their pool reads and their two chains of dependent adds
-            // overlap.  Replaces the terms pass, a barrier and the one-lane-per-cluster ordered sums (9 k of a 41 k-cycle step at HL).
-            else if (D <= 64) {
-                PH(2); FRESH_LANE_IDS();
-                const int q = lane;
-                const bool qon = q < D && flk[q] != 0;
-                const unsigned long long onmask = __ballot(qon);
-                constexpr int NW = T / 64;
-                for (int j = wave; j < nneed; j += 2 * NW) {
-                    int id_[2], cn_[2];
-                    double ta_[2] = {0.0, 0.0}, tb_[2] = {0.0, 0.0};
-                    bool have_[2];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        have_[u] = j + u * NW < nneed;
-                        id_[u] = have_[u] ? sh.need[j + u * NW] : 1;
-                        cn_[u] = have_[u] ? (int)s.cn[id_[u]] : 0;
-                    }
-                    if (d.kind == K_GAUSSIAN) {
-                        double2 sb_[2];
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) sb_[u] = (have_[u] && qon) ? ld2(s.sb, (size_t)id_[u] * D + q) : make_double2(0.0, 0.5);
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            if (have_[u] && qon) gauss_terms(sh.xs[q], (double)cn_[u], gauss_ml(cn_[u], sb_[u]), ta_[u], tb_[u]);
-                    } else if (d.kind == K_CATEGORICAL) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            if (have_[u] && qon) {
-                                const int x = ((const int *)sh.xs)[q];
-                                ta_[u] = glob(d.lhtab)[glob(d.maxcol)[q] + 2 * cn_[u]];                 // log(nlevels_q + n)
-                                const int c = s.cnt[((size_t)id_[u] * D + q) * d.L + (x - 1)];
-                                tb_[u] = (cn_[u] == 0) ? glob(d.lhtab)[1] : glob(d.lhtab)[2 * c + 1];   // log(0.5 + counts)
-                            }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            if (have_[u] && qon) ta_[u] = negbin_term(glob(d.lgtab), cn_[u], ((const int *)sh.xs)[q], s.nbs[(size_t)id_[u] * D + q]);
-                    }
-                    // the ordered sums (calc_logprob's loops), wave-uniform
-                    double out_[2];
-                    if (d.kind == K_GAUSSIAN) {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) out_[u] = (double)nflag * glob(d.gtab)[cn_[u]];      // gaussian_cluster.jl:38-40
-                        for (int qq = 0; qq < D; ++qq)
-                            if ((onmask >> qq) & 1ull) {
-#pragma unroll
-                                for (int u = 0; u < 2; ++u) { out_[u] += readlane_f64(ta_[u], qq); out_[u] -= readlane_f64(tb_[u], qq); }
-                            }
-                    } else if (d.kind == K_CATEGORICAL) {
-                        double acc_[2] = {0.0, 0.0};                                                     // categorical_cluster.jl:30
-                        for (int qq = 0; qq < D; ++qq)
-                            if ((onmask >> qq) & 1ull) {
-#pragma unroll
-                                for (int u = 0; u < 2; ++u) acc_[u] += readlane_f64(ta_[u], qq);
-                            }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) out_[u] = -acc_[u];
-                        for (int qq = 0; qq < D; ++qq)
-                            if ((onmask >> qq) & 1ull) {
-#pragma unroll
-                                for (int u = 0; u < 2; ++u) out_[u] += readlane_f64(tb_[u], qq);
-                            }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) out_[u] = 0.0;                                       // negbinom_cluster.jl:25
-                        for (int qq = 0; qq < D; ++qq)
-                            if ((onmask >> qq) & 1ull) {
-#pragma unroll
-                                for (int u = 0; u < 2; ++u) out_[u] += readlane_f64(ta_[u], qq);
-                            }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        if (have_[u] && lane == 0) sh.lpl[j + u * NW] = out_[u];
-                }
-                lds_barrier();
-            }
-#endif
             else {
                 const int RS = 2 * D + 1, D1 = D + 1;
                 int CH = a.terms_cap / RS;
@@ -1842,26 +1746,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 // label and all others the one-hot label -- the hand-off is a 16-byte header, no per-particle records
                 const bool hdr_only = XSPLIT && one && (int)sh.cdf[N + 1] >= 0;
                 if (hdr_only) xhdr = 1 | ((int)sh.cdf[N + 1] << 8);
-#ifdef PMDI_EXP_COLVOTE
-                // EXPERIMENT (default off): one class whose CDF row is one-hot at the reference label -> every particle takes that
-                // label; if every live column holds the same cluster under it (ncol table reads instead of a column index and a
-                // table entry per particle) the step is unanimous without looking at a particle: no draw loop, no second vote.
-                bool colsame = false;
-                if (one && (int)sh.cdf[N + 1] == ns0) {
-                    const int ncol = sh.kncol[k];
-                    int okc = 1;
-                    for (int c = tid; c < ncol; c += T) okc &= (part[(size_t)c * N + ns0] == c0) ? 1 : 0;
-                    colsame = __syncthreads_and(okc) != 0;
-                }
-                if (colsame) {
-                    const double inc = sh.cdf[N];                        // the class's log-increment (:227,:245)
-                    for (int p = tid; p < P; p += T) {
-                        if (!XSPLIT) sh.lw[p] = sh.lw[p] + inc;          // (split mode: the header alone carries this step, hdr_only)
-                        sh.news[k * P + p] = (unsigned char)ns0;
-                        s.sstar[(size_t)pos * P + p] = (unsigned char)ns0;   // (:265)
-                    }
-                } else
-#endif
                 for (int pb0 = 0; pb0 < P; pb0 += 4 * T) {       // four particles per lane, stage by stage: their
                     int ns_[4], c_[4], r_[4];                    // LDS chains and pool reads overlap
                     double inc_[4], lw_[4];
@@ -1923,11 +1807,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                 if (freshk) v = 1;                                           // curr_id += 1 (:267-269)
                 const bool needs = s.counts[c0] != P;                        // ncopies == counts ? (:286)
                 const int nnew = s.cn[c0] + 1;
-#ifdef PMDI_EXP_COLVOTE
-                ustep = colsame ? true : (__syncthreads_and(same) != 0);
-#else
                 ustep = __syncthreads_and(same) != 0;
-#endif
                 if (ustep) {
                     PH(13);
                     const int tgt = needs ? maxid + 1 : c0;                  // (:290-292)
@@ -2269,9 +2149,13 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
         if (tid == 0) {
             if (failed == 1) a.err[chain] = -4;                                     // PMDI_E_POOL
             else if (failed == 3) a.err[chain] = -6;                                // a partner workgroup never arrived
+            else if (failed == 2 && a.err[chain] == 0) a.err[chain] = -4;           // stopped with a partner that ran out of pool
             a.cost[chain] = clock64() - t_start;
             if (XSPLIT) __hip_atomic_fetch_add(gen(XCNT), 1 << 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // partners stop waiting
         }
+        // the chain keeps its allocations: a caller that goes on (device-resident chains) never reads an unwritten s_out
+        for (int k = 0; k < K; ++k)
+            for (long long pp = tid; pp < n; pp += T) a.s_out[((size_t)chain * Kf + kd0 + k) * n + pp] = s_in[(size_t)k * n + pp];
         return;
     }
 
@@ -2329,25 +2213,44 @@ size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T)
     return c.total;
 }
 
-hipError_t pmdi_launch_sweep(const SweepArgs &a_in, SweepArgs *d_args, int n_chains, int T, hipStream_t stream)
+static const void *sweep_kernel_for(const SweepArgs &a, int T)
+{
+    const bool two = a.two_per_cu != 0;
+    const bool k1 = a.K == 1 || a.ksplit;      // one dataset per workgroup
+    if (T == 1024) return k1 ? (const void *)pmdi_sweep_kernel<1024, 4, true> : (const void *)pmdi_sweep_kernel<1024, 4, false>;
+    if (T == 512 && two) return k1 ? (const void *)pmdi_sweep_kernel<512, 4, true> : (const void *)pmdi_sweep_kernel<512, 4, false>;
+    if (T == 512) return k1 ? (const void *)pmdi_sweep_kernel<512, 2, true> : (const void *)pmdi_sweep_kernel<512, 2, false>;
+    if (T == 128) return k1 ? (const void *)pmdi_sweep_kernel<128, 2, true> : (const void *)pmdi_sweep_kernel<128, 2, false>;
+    if (T == 256) return k1 ? (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, true> : (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, false>;
+    return nullptr;
+}
+
+hipError_t pmdi_sweep_blocks_per_cu(const SweepArgs &a, int T, int *blocks)
+{
+    const void *fn = sweep_kernel_for(a, T);
+    if (!fn) return hipErrorInvalidValue;
+    const size_t lds = pmdi_sweep_lds_bytes(a, T);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fn, T, lds);
+}
+
+hipError_t pmdi_launch_sweep(const SweepArgs &a_in, SweepArgs *d_args, int n_chains, int T, hipStream_t stream, SweepArgs *staging)
 {
     SweepArgs a = a_in;
-    a.n_slots = n_chains;
+    if (!a.ksplit || a.n_slots <= 0) { a.n_slots = n_chains; a.slot_base = 0; }   // (a split launch in batches says which slots are its own)
     const size_t lds = pmdi_sweep_lds_bytes(a, T);
-    const bool two = a.two_per_cu != 0;
-    const void *fn = nullptr;
-    const bool k1 = a.K == 1 || a.ksplit;      // one dataset per workgroup
-    if (T == 1024) fn = k1 ? (const void *)pmdi_sweep_kernel<1024, 4, true> : (const void *)pmdi_sweep_kernel<1024, 4, false>;
-    else if (T == 512 && two) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 4, true> : (const void *)pmdi_sweep_kernel<512, 4, false>;
-    else if (T == 512) fn = k1 ? (const void *)pmdi_sweep_kernel<512, 2, true> : (const void *)pmdi_sweep_kernel<512, 2, false>;
-    else if (T == 128) fn = k1 ? (const void *)pmdi_sweep_kernel<128, 2, true> : (const void *)pmdi_sweep_kernel<128, 2, false>;
-    else if (T == 256) fn = k1 ? (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, true> : (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, false>;
-    else return hipErrorInvalidValue;
+    const void *fn = sweep_kernel_for(a, T);
+    if (!fn) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     // the argument block lives in device memory (stream-ordered copy), the kernel gets a pointer:
-    // cold-path device functions then read what they need instead of holding it in registers
-    e = hipMemcpyAsync(d_args, &a, sizeof(SweepArgs), hipMemcpyHostToDevice, stream);
+    // cold-path device functions then read what they need instead of holding it in registers.  Through a pinned staging
+    // slot the copy is asynchronous for the host too (from a stack object it is not: the runtime copies pageable memory
+    // before it returns).
+    const SweepArgs *src = &a;
+    if (staging) { *staging = a; src = staging; }
+    e = hipMemcpyAsync(d_args, src, sizeof(SweepArgs), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
     const SweepArgs *ap = d_args;
     void *args[] = {(void *)&ap};

@@ -225,6 +225,7 @@ function pmdi_device(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float
     K = length(dataFiles)
     n_obs = size(dataFiles[1], 1)
     dataNames === nothing && (dataNames = ["K$i" for i in 1:K])
+    @assert length(dataNames) == K "Number of data names not equal to number of datasets"
     @assert length(dataTypes) == K "Number of datatypes not equal to number of datasets"
     @assert all(size(d, 1) == n_obs for d in dataFiles) "Datasets don't have same number of observations. Each row must correspond to the same underlying observational unit across datasets."
     @assert 0 < ρ < 1 "ρ must be between 0 and 1"
@@ -247,8 +248,11 @@ function pmdi_device(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float
     try
         check(ccall((:pmdi_gibbs_create, LIB), Cint, (Ptr{Cvoid}, Float64, Int32, Ref{Ptr{Cvoid}}),
                     h, ρ, featureSelect === nothing ? 0 : 1, g))                 # src/pmdi.jl:59-66, 95-96, 106-110
-        names = [Base.unsafe_convert(Cstring, String(nm)) for nm in dataNames]
-        GC.@preserve dataNames begin
+        # own the strings whose pointers cross the ABI (String(nm) of a SubString or Symbol is a temporary: rooting
+        # `dataNames` would not keep it alive)
+        strs = String[String(nm) for nm in dataNames]
+        names = [Base.unsafe_convert(Cstring, st) for st in strs]
+        GC.@preserve strs begin
             check(ccall((:pmdi_csv_open, LIB), Cint, (Cstring, Int32, Int64, Ptr{Cstring}, Ref{Ptr{Cvoid}}),
                         outputFile, K, n_obs, names, csv))                       # :147-156
             if featureSelect !== nothing

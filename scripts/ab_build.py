@@ -9,9 +9,9 @@ Then, on the GPU box, run the variants back to back in one gpurun call (same box
         python scripts/bline.py $v < gpurun_out/ab.json
     done
 
-Default-off experiments waiting for their first GPU run (round 3): -DPMDI_EXP_LAZY_KS, -DPMDI_EXP_WAVE_SUM, -DPMDI_EXP_COLVOTE, -DPMDI_EXP_LEAF_ALIAS
-(DESIGN.md section 9); each must pass `pytest tests/test_gpu_sweep.py tests/test_gpu_soak.py -m gpu` with PMDI_LIB_PATH set before its
-bench number means anything.
+A variant must pass `pytest tests/test_gpu_sweep.py tests/test_gpu_soak.py -m gpu` with PMDI_LIB_PATH set before its bench number means
+anything.  (Round 3: the lazy-address KS went through exactly that -- 36 tests equal, HL 459.9 -> 495.6 it/s -- and is the default now;
+the other round-2 experiments were deleted unrun: the settled-chain kernel replaces what they patched.)
 
 PMDI_NO_BUILD=1 keeps the box from rebuilding a variant from the (different) sources that travelled with it.  build_ab/ is
 git-ignored but travels with gpurun.  (Round 2: column table 469.8 / +uniform log-weights 465.4 / +LDS mirrors 442.1 it/s.)

@@ -1,12 +1,12 @@
 """Where do the register spills of the sweep kernel sit?  Compiles pmdi_sweep.hip with line tables (no GPU needed) and maps
 every scratch_store / scratch_load of the chosen builds to its source line.
 
-    python scripts/spill_sites.py [extra hipcc flags, e.g. -DPMDI_EXP_LAZY_KS]
+    python scripts/spill_sites.py [extra hipcc flags]
 
 Round 2: in the 256-register build `<256,2,false>` 22 of the 36 scratch stores sit on make_ks() (pmdi_device.h) -- the 22
 wave-uniform pointers of a (chain, dataset), computed at the top of EVERY step and parked in scratch: 22 stores x 256 lanes x
 4 B = 22 KB per chain and step, about half of the spill write-back that dominates WRITE_SIZE (profiles/README.md).  With
--DPMDI_EXP_LAZY_KS (addresses rebuilt from the argument block where they are used) the kernel body has 5 stores / 6 loads.
+the addresses rebuilt from the argument block where they are used (round 3 default) the kernel body has 5 stores / 6 loads.
 (Its first version loaded the argument block through a generic pointer: 4 000 extra flat_load instructions instead of s_load --
 caught by the instruction-class line below, fixed by going through the constant address space.)
 """

@@ -49,3 +49,18 @@ def t5_invariants(state, N, P, K, n_obs):
             assert state["cluster_n"][k, part[j] - 1].sum() == n_obs        # :147,:156
         cnt = np.bincount(part.ravel(), minlength=cap + 1)[1:cap + 1]
         assert (cnt == state["counts"][k][:cap]).all()                    # :149-153,:158-162
+
+
+def expected_work_counters(rec, trace, N, item_cap="auto"):
+    """What the device's work counters [WK_EVAL, WK_COLS, WK_SPLITS] must equal, per dataset, from the oracle's per-step record
+    (pmdi_oracle_debug_steps) and trace of the same sweep.  Clusters evaluated: the clusters the class leaders read at
+    src/pmdi.jl:232 -- or every live id in a step whose (class, label) items outgrow the LDS tables (item_cap; None = never).
+    Columns met by resampling events: the distinct columns of particle[:, :, k] before each event.  Copy-on-write splits: the
+    growth of the distinct-column count inside the steps (a step never merges columns; a resampling only drops them)."""
+    if item_cap == "auto":
+        item_cap = 384 if N > 32 else 256
+    ncls, need, cols_pre, cols_post, maxid = rec[:, :, 0], rec[:, :, 1], rec[:, :, 4], rec[:, :, 5], rec[:, :, 6]
+    ev = need if item_cap is None else np.where(ncls * N <= item_cap, need, maxid)
+    res = trace[:, 1] > 0
+    prev = np.vstack([np.ones((1, rec.shape[1]), dtype=rec.dtype), cols_post[:-1]])
+    return ev.sum(axis=0), cols_pre[res].sum(axis=0), (cols_pre - prev).sum(axis=0)

@@ -11,12 +11,14 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "particlemdi.jl_amd", "csrc", "pmdi_sweep.hip")
 BUDGET = {            # (T, WPS, K1) -> max VGPR spill slots as `-Rpass-analysis=kernel-resource-usage` reports them for the kernel (the
-    # figure covers the out-of-line device functions it calls: dropping two stores from the resampling function alone moved the
-    # 256-thread build from 63 to 27).  Measured 203 / 46 / 29 with the particle -> cluster table kept by column (round 2, late:
-    # the copy-on-write split is inlined twice into the step loop); 166 / 17 / 15 before that; 124 / 8 / 9 in round 1.
-    "ILi512ELi4ELb1": 225,
-    "ILi512ELi2ELb1": 48,
-    "ILi256ELi2ELb1": 30,
+    # figure covers the out-of-line device functions it calls).  Round 3: the per-(chain, dataset) array addresses are rebuilt from
+    # the argument block where they are used (pmdi_device.h, LazyArr) instead of being parked in scratch at the top of every step:
+    # measured 166 / 75 / 13 (round 2: 203 / 46 / 29; HL +7.8 % on the GPU, the 256-register wide build pays for it).  The light
+    # build is at the <= 16 the round-2 review asked for; settled chains no longer run on these builds at all when the settled-chain
+    # kernel (pmdi_sweep2.hip) takes them.
+    "ILi512ELi4ELb1": 170,
+    "ILi512ELi2ELb1": 80,
+    "ILi256ELi2ELb1": 16,
 }
 
 
@@ -44,10 +46,3 @@ def test_spill_budget_of_the_sweep_kernel_builds():
     for variant, limit in BUDGET.items():
         assert variant in spills, (variant, sorted(spills))
         assert spills[variant] <= limit, f"pmdi_sweep_kernel<{variant}> spills {spills[variant]} VGPRs (budget {limit})"
-
-
-def test_the_lazy_address_experiment_still_builds_and_spills_less():
-    """-DPMDI_EXP_LAZY_KS (pmdi_device.h; default off, first A/B of the next round): the per-(chain, dataset) array addresses are
-    rebuilt where they are used instead of being parked in scratch at the top of every step.  Measured 160 / 71 / 11."""
-    spills = _spills(["-DPMDI_EXP_LAZY_KS"])
-    assert spills["ILi256ELi2ELb1"] <= 15 and spills["ILi512ELi4ELb1"] <= 190

@@ -157,23 +157,108 @@ def test_baseline_configs_reduced_vs_oracle(pkg, O, cfg, scale, P):
 # src/pmdi.jl:63-66: its first sweep from a random start (thousands of live clusters at P = 4 096, N = 50) costs the
 # oracle minutes, which the GPU test budget does not have.
 FULL = {"cfg3": 3, "HL": 3, "cfg4": 2, "cfg5": 1}
+SIZES = {"cfg3": (5000, 30, 1024), "HL": (10000, 20, 1024), "cfg4": (10000, 50, 2048), "cfg5": (20000, 50, 4096)}
 
 
-@pytest.mark.parametrize("cfg", ["cfg3", "HL", "cfg4", "cfg5"])
-def test_full_size_mid_chain_iteration_vs_oracle(pkg, O, cfg):
+def _one_iteration_vs_oracle(pkg, O, w, sw, g, chains, it, base_seed, fsel, tag):
+    """ONE whole Gibbs iteration of the device-resident chains `chains`, compared piece by piece with the oracle from the same
+    state: hyper-parameter kernel, sweep (allocations, p_star, counters, work counters, log-weights, exported state, T5
+    invariants), feature selection, label alignment."""
+    from _cases import expected_work_counters
+    n, K, N, P = w["n"], w["K"], w["N"], w["P"]
+    n1 = g.n1
+    st0 = {c: g.get(c) for c in chains}
+    g.step(pkg.STEP_BEGIN); g.step(pkg.STEP_HYPERS)
+    st1 = {c: g.get(c) for c in chains}
+    hys = {}
+    for c in chains:
+        # ---- hyper-parameter kernel against the literal N^K restatement from the same state
+        hy = O.Hypers(n, N, K, seed=base_seed + c)
+        a = st0[c]
+        hy.M, hy.gamma, hy.gamma0, hy.Phi, hy.v, hy.Z = a["M"], a["gamma"], a["gamma0"], a["Phi"], a["v"], a["Z"]
+        hy.s[:] = a["s"]; hy.order[:] = a["order"]
+        hy.step(it)
+        b = st1[c]
+        assert (b["order"] == np.array(hy.order)).all()
+        for key in ("M", "gamma", "Phi"):
+            assert np.allclose(b[key], getattr(hy, key), rtol=1e-9), key
+        assert np.isclose(b["v"], hy.v, rtol=1e-9) and np.isclose(b["Z"], hy.Z, rtol=1e-9)
+        hys[c] = hy
+    g.step(pkg.STEP_SWEEP)
+    res = g.results()
+    work = sw.work_counters()
+    oracles = {}
+    for c in chains:
+        # ---- the sweep at full size: same inputs on both sides (the device's post-update hyper-parameters)
+        b = st1[c]
+        Pi = b["gamma"] / b["gamma"].sum(axis=0, keepdims=True)
+        orc = O.Oracle(w["data"], w["kinds"], N, P, seed=base_seed + c)
+        rec = orc.debug_steps(n - n1 + 1)
+        flags = [b["flags"][sum(w["D"][:k]):sum(w["D"][:k + 1])] for k in range(K)]
+        ro = orc.sweep(it, b["s"], b["order"], n1, Pi, b["Phi"], flags, lw_init=1.0, trace=True)
+        st2 = g.get(c)
+        print(f"{tag}: chain {c}, oracle sweep {ro['stats']['seconds']:.1f} s, stats {ro['stats']}")
+        if not (st2["s"] == ro["s"]).all():
+            # where did the chain leave the oracle?  (shuffled position of the first differing allocation, per dataset)
+            pos_of = np.empty(n, dtype=np.int64); pos_of[b["order"] - 1] = np.arange(n)
+            first = [int(pos_of[np.where(st2["s"][:, k] != ro["s"][:, k])[0]].min()) if (st2["s"][:, k] != ro["s"][:, k]).any() else -1 for k in range(K)]
+            raise AssertionError(f"{tag}: chain {c}: allocations differ from the oracle at full size; first differing shuffled position per "
+                                 f"dataset {first} (swept positions start at {n1 - 1}); device stats {res['stats'][c].tolist()} oracle {ro['stats']}")
+        assert int(res["p_star"][c]) == ro["p_star"]
+        for j, key in enumerate(("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")):
+            assert res["stats"][c, j] == ro["stats"][key], key
+        assert np.allclose(res["logweight"][c], ro["logweight"], rtol=1e-6, atol=1e-6)       # north_star tolerance
+        wk = work[c]
+        up, mv = orc.work()
+        ev, cols, splits = expected_work_counters(rec, ro["trace"], N)
+        assert (wk[:, 1] == up).all() and (wk[:, 3] == mv).all() and wk[:, 2].sum() == ro["stats"]["n_clones"]
+        assert (wk[:, 0] == ev).all() and (wk[:, 5] == cols).all() and (wk[:, 6] == splits).all(), (wk, ev, cols, splits)
+        dev_state, ora_state = sw.export_state(c), orc.export()
+        t5_invariants(dev_state, N, P, K, n)
+        assert (dev_state["particle"] == ora_state["particle"]).all()
+        assert (dev_state["max_id"] == ora_state["max_id"]).all()
+        for k in range(K):
+            m = int(ora_state["max_id"][k])
+            assert (dev_state["counts"][k][:m] == ora_state["counts"][k][:m]).all()
+            assert (dev_state["cluster_n"][k][:m] == ora_state["cluster_n"][k][:m]).all()
+        oracles[c] = (orc, ro)
+    # ---- feature selection (cfg5) and label alignment from the same state
+    if fsel:
+        g.step(pkg.STEP_FEATSEL)
+        for c in chains:
+            of, _ = oracles[c][0].feature_select(it, oracles[c][1]["s"])
+            assert (g.get(c)["flags"] == np.concatenate(of)).all()
+    g.step(pkg.STEP_ALIGN)
+    for c in chains:
+        hy = hys[c]
+        hy.s[:] = oracles[c][1]["s"]
+        hy.gamma, hy.Phi = st1[c]["gamma"], st1[c]["Phi"]
+        hy.align_labels(it)
+        st3 = g.get(c)
+        assert (st3["s"] == np.array(hy.s)).all() and (st3["gamma"] == hy.gamma).all()
+        oracles[c][0].close(); hy.close()
+    return {c: oracles[c][1] for c in chains}
+
+
+@pytest.mark.parametrize("cfg,ksplit", [("cfg3", 0), ("cfg3", 1), ("HL", 0), ("HL", 1), ("cfg4", 0), ("cfg4", 1), ("cfg5", None)])
+def test_full_size_mid_chain_iteration_vs_oracle(pkg, O, cfg, ksplit, monkeypatch):
     """BASELINE.json's configs at their FULL sizes (n, K, D, N, P as stated; cfg4: P = 2 048, N = 50; cfg5: P = 4 096,
     N = 50, D = 200, feature selection on): a chain is burnt in on the device, then ONE whole iteration is compared
-    piece by piece with the oracle from the same state -- hyper-parameter kernel, sweep (allocations, p_star,
-    counters, log-weights, T5 invariants on the exported state), feature selection, label alignment."""
+    piece by piece with the oracle from the same state.  K > 1 configs run in BOTH forms of the sweep: PMDI_KSPLIT=0 = one
+    workgroup per chain (the form bench.py's `value` is timed on: the K datasets inside one workgroup, heavy / light launch
+    groups) and PMDI_KSPLIT=1 = K cooperating workgroups per chain (what a small batch gets by default)."""
     from particlemdi_jl_amd import workloads
     w = workloads.make(cfg)
     n, K, N, P = w["n"], w["K"], w["N"], w["P"]
-    assert (n, N, P) == {"cfg3": (5000, 30, 1024), "HL": (10000, 20, 1024), "cfg4": (10000, 50, 2048), "cfg5": (20000, 50, 4096)}[cfg]
+    assert (n, N, P) == SIZES[cfg]
+    if ksplit is not None:
+        monkeypatch.setenv("PMDI_KSPLIT", str(ksplit))
     fsel = cfg == "cfg5"
     base_seed, C = 41, (4 if P <= 1024 else 2)
     sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=C, seed=base_seed)
+    if ksplit is not None:
+        assert sw.split == bool(ksplit)
     g = pkg.Gibbs(sw, rho=0.25, feature_select=fsel)
-    n1 = g.n1
     if cfg == "cfg5":
         rng = np.random.default_rng(2)
         for cc in range(C):
@@ -185,54 +270,25 @@ def test_full_size_mid_chain_iteration_vs_oracle(pkg, O, cfg):
     # the chain whose last burn-in sweep resampled most (a chain can collapse into one cluster per dataset, where
     # every step is unanimous and nothing is resampled: not the state this test is after)
     c = int(np.argmax(g.results()["stats"][:, 1]))
-    seed = base_seed + c
-    it = FULL[cfg] + 1
-    st0 = g.get(c)
-    # ---- hyper-parameter kernel against the literal N^K restatement from the same state
-    hy = O.Hypers(n, N, K, seed=seed)
-    hy.M, hy.gamma, hy.gamma0, hy.Phi, hy.v, hy.Z = st0["M"], st0["gamma"], st0["gamma0"], st0["Phi"], st0["v"], st0["Z"]
-    hy.s[:] = st0["s"]; hy.order[:] = st0["order"]
-    hy.step(it)
-    g.step(pkg.STEP_BEGIN); g.step(pkg.STEP_HYPERS)
-    st1 = g.get(c)
-    assert (st1["order"] == np.array(hy.order)).all()
-    for key in ("M", "gamma", "Phi"):
-        assert np.allclose(st1[key], getattr(hy, key), rtol=1e-9), key
-    assert np.isclose(st1["v"], hy.v, rtol=1e-9) and np.isclose(st1["Z"], hy.Z, rtol=1e-9)
-    # ---- the sweep at full size: same inputs on both sides (the device's post-update hyper-parameters)
-    Pi = st1["gamma"] / st1["gamma"].sum(axis=0, keepdims=True)
-    orc = O.Oracle(w["data"], w["kinds"], N, P, seed=seed)
-    flags = [st1["flags"][sum(w["D"][:k]):sum(w["D"][:k + 1])] for k in range(K)]
-    ro = orc.sweep(it, st1["s"], st1["order"], n1, Pi, st1["Phi"], flags, lw_init=1.0)
-    g.step(pkg.STEP_SWEEP)
-    res = g.results()
-    st2 = g.get(c)
-    print(f"{cfg}: chain {c}, oracle sweep {ro['stats']['seconds']:.1f} s, stats {ro['stats']}")
-    assert (st2["s"] == ro["s"]).all(), f"{cfg}: allocations differ from the oracle at full size"
-    assert int(res["p_star"][c]) == ro["p_star"]
-    for j, key in enumerate(("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")):
-        assert res["stats"][c, j] == ro["stats"][key], key
-    assert np.allclose(res["logweight"][c], ro["logweight"], rtol=1e-6, atol=1e-6)       # north_star tolerance
-    assert ro["stats"]["n_resamples"] > 0 and ro["stats"]["n_operations"] > 2 * K * (n - n1 + 1)   # a genuinely mid-chain state
-    wk = sw.work_counters()[c]
-    assert wk[:, 2].sum() == ro["stats"]["n_clones"] and (wk[:, 0] <= res["stats"][c, 0]).all()
-    dev_state, ora_state = sw.export_state(c), orc.export()
-    t5_invariants(dev_state, N, P, K, n)
-    assert (dev_state["particle"] == ora_state["particle"]).all()
-    assert (dev_state["max_id"] == ora_state["max_id"]).all()
-    for k in range(K):
-        m = int(ora_state["max_id"][k])
-        assert (dev_state["counts"][k][:m] == ora_state["counts"][k][:m]).all()
-        assert (dev_state["cluster_n"][k][:m] == ora_state["cluster_n"][k][:m]).all()
-    # ---- feature selection (cfg5) and label alignment from the same state
-    if fsel:
-        g.step(pkg.STEP_FEATSEL)
-        of, _ = orc.feature_select(it, ro["s"])
-        assert (g.get(c)["flags"] == np.concatenate(of)).all()
-    hy.s[:] = ro["s"]
-    hy.gamma, hy.Phi = st1["gamma"], st1["Phi"]
-    hy.align_labels(it)
-    g.step(pkg.STEP_ALIGN)
-    st3 = g.get(c)
-    assert (st3["s"] == np.array(hy.s)).all() and (st3["gamma"] == hy.gamma).all()
-    g.close(); sw.close(); orc.close(); hy.close()
+    ro = _one_iteration_vs_oracle(pkg, O, w, sw, g, [c], FULL[cfg] + 1, base_seed, fsel, f"{cfg}/ksplit={ksplit}")[c]
+    assert ro["stats"]["n_resamples"] > 0 and ro["stats"]["n_operations"] > 2 * K * (n - g.n1 + 1)   # a genuinely mid-chain state
+    g.close(); sw.close()
+
+
+def test_headline_shape_many_chains_three_launch_groups(pkg, O):
+    """The shape bench.py times: HL with hundreds of chains on one GPU -- one workgroup per chain (the throughput form), the
+    chains of a sweep dealt to the heaviest / heavy / light (settled) launches by what their previous sweep looked like, the start
+    gate between the launches.  After a short burn-in one whole iteration of three chains (the one that resampled most, the
+    costliest and a median one) is compared with the oracle."""
+    from particlemdi_jl_amd import workloads
+    w = workloads.make("HL")
+    base_seed, C, burn = 77, 640, 4
+    sw = pkg.Sweeper(w["data"], w["kinds"], w["N"], w["P"], n_chains=C, seed=base_seed)
+    assert not sw.split
+    g = pkg.Gibbs(sw, rho=0.25)
+    g.iterate(burn)
+    stats = g.results()["stats"]
+    costs = sw.chain_costs()
+    chains = sorted({int(np.argmax(stats[:, 1])), int(np.argmax(costs)), int(np.argsort(costs)[C // 2])})
+    _one_iteration_vs_oracle(pkg, O, w, sw, g, chains, burn + 1, base_seed, False, f"HL x {C} chains")
+    g.close(); sw.close()

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from _cases import golden_cases, load_golden, replay, t5_invariants
+from _cases import expected_work_counters, golden_cases, load_golden, replay, t5_invariants
 from conftest import make_mixed, random_hypers
 
 pytestmark = pytest.mark.gpu
@@ -42,6 +42,7 @@ def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, b
     o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1, q2_mode=q2)
     Dcum = np.cumsum([d.shape[1] for d in data])[:-1]
     s = rng.integers(1, N + 1, size=(n, K))
+    rec = o.debug_steps(n - n1 + 1)
     for it in range(1, iters + 1):
         order = rng.permutation(n) + 1
         Pi, Phi = random_hypers(rng, N, K)
@@ -57,10 +58,11 @@ def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, b
         # the work counters behind bench.py's algorithmic byte count: clusters updated / cloned / moved per dataset
         wk, (up, mv) = g.sw.work_counters()[0], o.work()
         assert (wk[:, 1] == up).all() and (wk[:, 3] == mv).all() and wk[:, 2].sum() == ro["stats"]["n_clones"]
-        assert (wk[:, 0] >= 1).all() and wk[:, 0].sum() <= ro["stats"]["n_operations"]      # evaluated <= the reference's count
-        # the particle -> cluster table is kept by distinct column: every resampling event meets 1..P live columns per dataset
-        nres = ro["stats"]["n_resamples"]
-        assert (wk[:, 5] >= nres).all() and (wk[:, 5] <= nres * P).all() and (wk[:, 6] >= 0).all()
+        # ... and, pinned to the oracle's per-step record: clusters evaluated (the ones a class leader reads at src/pmdi.jl:232),
+        # distinct columns of particle[:, :, k] met by the resampling events, columns made by copy-on-write splits
+        ev, cols, splits = expected_work_counters(rec, ro["trace"], N)
+        assert (wk[:, 0] == ev).all(), (wk[:, 0], ev)
+        assert (wk[:, 5] == cols).all() and (wk[:, 6] == splits).all(), (wk[:, 5:7], cols, splits)
         s = ro["s"]
     if check_state:
         eg, eo = g.sw.export_state(0), o.export()
@@ -278,3 +280,27 @@ def test_device_pointer_entry_matches_host_entry(pkg, O):
     assert (so.cpu().numpy()[0].T + 1 == want["s"]).all()
     assert int(ps.item()) + 1 == want["p_star"]
     assert int(st[0, 0].item()) == want["stats"]["n_operations"]
+
+
+def test_split_form_stops_all_partners_when_one_runs_out_of_pool(pkg, monkeypatch):
+    """K cooperating workgroups per chain (PMDI_KSPLIT=1): when one dataset's pool overflows, its workgroup poisons the chain's
+    arrival counter and the partners stop at their next hand-off -- PMDI_E_POOL comes back at once, nobody sits out the
+    20-second watchdog of the hand-off."""
+    import time
+    monkeypatch.setenv("PMDI_KSPLIT", "1")
+    rng = np.random.default_rng(4)
+    n, N, P = 200, 10, 256
+    z = rng.integers(0, 3, n)
+    data = [rng.normal(size=(n, 4)), rng.normal(size=(n, 4)) + 6.0 * (z[:, None] - 1), rng.normal(size=(n, 3)) + 6.0 * (z[:, None] - 1)]
+    sw = pkg.Sweeper(data, ["gaussian"] * 3, N, P, n_chains=3, pool_cap=N + 6)     # dataset 0 has no structure: its pool grows
+    assert sw.split
+    s = np.repeat(np.repeat((z + 1)[None, :, None], 3, axis=2), 3, axis=0)
+    s[:, :, 0] = rng.integers(1, N + 1, size=(3, n))
+    order = np.stack([rng.permutation(n) + 1 for _ in range(3)])
+    hyp = [random_hypers(rng, N, 3) for _ in range(3)]
+    t0 = time.perf_counter()
+    with pytest.raises(pkg.PmdiError) as e:
+        sw.sweep(1, s, order, 50, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]))
+    assert e.value.code == -4                         # PMDI_E_POOL
+    assert time.perf_counter() - t0 < 10.0            # ... not the watchdog
+    sw.close()

@@ -150,3 +150,35 @@ def test_distinct_column_counter_matches_the_exported_table(O):
             part = o.export()["particle"]
             assert [len({tuple(col) for col in part[k]}) for k in range(K)] == list(buf[-1])
     o.L.pmdi_oracle_debug_columns(o.h, None)
+
+
+def test_per_step_record_adds_up_to_the_sweep_counters(O):
+    """pmdi_oracle_debug_steps (what the device's work counters are checked against): its per-step columns add up to the sweep's
+    own counters, its column counts equal the older per-observation hook's, and a unanimous step has one chosen cluster."""
+    import ctypes as C
+    rng = np.random.default_rng(22)
+    data, kinds = make_mixed(rng, 160)
+    N, P, K, n, n1 = 7, 128, 3, 160, 40
+    o = O.Oracle(data, kinds, N, P, seed=5)
+    rec = o.debug_steps(n - n1 + 1)
+    cols = np.zeros((n - n1 + 1, K), dtype=np.int64)
+    o.L.pmdi_oracle_debug_columns(o.h, cols.ctypes.data)
+    s = rng.integers(1, N + 1, size=(n, K))
+    for it in range(1, 4):
+        Pi, Phi = random_hypers(rng, N, K)
+        r = o.sweep(it, s, rng.permutation(n) + 1, n1, Pi, Phi, trace=True)
+        s = r["s"]
+        st, tr = r["stats"], r["trace"]
+        up, _ = o.work()
+        assert rec[:, :, 0].sum() == st["sum_classes"] and rec[:, :, 6].sum() == st["n_operations"]
+        assert (rec[:, :, 2].sum(axis=0) == up).all() and rec[:, :, 3].sum() == st["n_clones"]
+        assert (rec[:, :, 4] == cols).all()
+        assert (rec[:, :, 1] >= 1).all() and (rec[:, :, 1] <= rec[:, :, 6]).all()          # reachable clusters: some, never more than live ids
+        assert (rec[:, :, 1] <= rec[:, :, 0] * N).all()
+        assert (rec[rec[:, :, 7] == 1][:, 2] == 1).all()                                      # unanimous: one chosen cluster
+        res = tr[:, 1] > 0
+        assert (rec[~res][:, :, 5] == rec[~res][:, :, 4]).all() and (rec[res][:, :, 5] <= rec[res][:, :, 4]).all()
+        # the classes column is the number of classes at the START of a step = the trace's count after the previous one
+        assert (rec[1:, :, 0] == tr[:-1, 2 + K:2 + 2 * K]).all()
+    o.L.pmdi_oracle_debug_columns(o.h, None)
+    o.debug_steps(0)
