@@ -242,19 +242,9 @@ def test_a_failed_chain_keeps_its_state_and_its_error_sticks(pkg):
     assert e.value.code == -4                         # PMDI_E_POOL, although later sweeps of the chain may have succeeded
     st = g.get(0)
     assert st["s"].min() >= 1 and st["s"].max() <= N
-    assert sorted(np.unique(st["s"])) == sorted(np.unique(s0)) or True      # (labels may have been re-aligned; the range is the check)
     g.set(0, s=s0); g.set(1, s=s0)                    # a chain given a new state starts without its sticky error
+    g.results()
+    # the handle outlives what was made from it: pmdi_destroy refuses (PMDI_E_STATE) while the pmdi_gibbs is alive
+    assert pkg.lib().pmdi_destroy(sw.h) == -6
     g.close()
-    with pytest.raises(pkg.PmdiError):                # the handle outlives what was made from it
-        pkg.lib().pmdi_destroy.restype = int
-        rc = pkg.lib().pmdi_destroy(sw.h)
-        g2 = None
-        if rc != 0:
-            raise pkg.PmdiError(rc, "unexpected")
-        sw.h = None
-        sw2 = pkg.Sweeper([x], ["gaussian"], N, P, n_chains=1)
-        g2 = pkg.Gibbs(sw2, rho=0.25)
-        rc = pkg.lib().pmdi_destroy(sw2.h)
-        assert rc == -5                               # PMDI_E_STATE: a pmdi_gibbs made from the handle is still alive
-        g2.close(); sw2.close()
-        raise pkg.PmdiError(rc, "destroy refused while a child is alive")
+    sw.close()
