@@ -70,6 +70,19 @@ struct DsetDev {
     size_t o_dl;            // int  [3][P]  distinct chosen ids this step: src, dst, new n
 };
 
+// LDS layout of the settled-chain kernel (pmdi_sweep2_body.h: make_layout fills it on the host, the kernel reads it from the
+// argument block): byte offsets into the workgroup's LDS
+struct S2Layout {
+    int red, sc, stat, wk, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, xfl;
+    int tr, tr_stride, tr_tb, tr_cdf, tr_bytes;       // transient region: per dataset tb rows + CDF rows; aliased by the resampling scratch
+    int rs_jtab, rs_raw, rs_anc, rs_hist;             // resampling scratch inside the transient region
+    int ds0, ds_stride;                               // dataset blocks
+    // offsets inside a dataset block
+    int tab, cmask, wmask, cbi, counts, cn, ncop, firstp, tgt, slotmap, ta, tax, lp, slot_id, slot_cn, slot_g, clsval, clslead, leadcol,
+        minp, nidv, knew, itemj, clist, klist, kval, krep, bmc, bmf, xid, dsc;
+    int Dp, cols_l, idcap, total;
+};
+
 struct SweepArgs {
     int K, N, P, cap;
     int Dmax, sumD, npairs, q1, q2, trace_on;
@@ -117,6 +130,8 @@ struct SweepArgs {
                                 // wait for the heaviest chains' workgroups to have been placed (a whole CU each) before they start
     int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
     int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
+    S2Layout s2;                // settled-chain kernel: its LDS layout (cols_l / idcap = columns / cluster ids kept in LDS)
+    int requeue_only;           // 1: this launch of the general kernel sweeps the chains the settled-chain kernel gave back (err == 1)
     int slot_base;              // split mode launched in residency-sized batches: first chain slot of this launch
     int err_keep;               // 1: a successful sweep leaves err[chain] as it is (device-resident chains: the first error sticks)
 };

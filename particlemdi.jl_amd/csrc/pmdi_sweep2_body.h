@@ -1,0 +1,1422 @@
+// pmdi_sweep2_body.h -- the conditional-SMC sweep for SETTLED chains (round 3): the same sweep as pmdi_sweep.hip
+// (src/pmdi.jl:165-171, 188-350, 373; src/misc.jl:15-59), re-designed around what a settled chain looks like (scripts/step_stats.py:
+// 1-2 particle classes, <= 8 clusters a class leader can reach, 6-40 distinct columns of particle[:, :, k], ids below ~200):
+//
+//   * one 256-thread workgroup per chain, PPL = P / 256 consecutive particles per lane, their state (log-weight, column index
+//     and class slot per dataset) in REGISTERS for the whole sweep;
+//   * the K datasets of an observation run CONCURRENTLY: wave k owns dataset k for everything per cluster (lanes = features):
+//     the clusters a class leader can reach are cached in that wave's registers (Sigma, beta, mu, lambda per feature) under a
+//     stable slot per cluster id, so a step evaluates one log per (cluster, feature) and reads no pool memory; ordered sums
+//     (calc_logprob's feature loop, bit-identical) by one lane per cluster from an LDS transposition; the class CDFs by shuffles;
+//   * the draw, the census of the chosen clusters and the Phi / ESS work run on all lanes for all K datasets at once; every
+//     per-id / per-column / per-(class, label) table is DIRECT-INDEXED in LDS (ids and columns are small here); what exceeds
+//     the LDS capacities (columns >= cols_l, ids >= idcap) lives in the chain's arena with the same indexing (slower, rare);
+//   * three workgroup barriers per swept observation (cluster phase | particle phase | bookkeeping phase);
+//   * resampling (src/misc.jl:27-47, src/pmdi.jl:317-341): weights stay in registers, Julia's pairwise cumsum as lane-serial
+//     leaf scans, the exact u += 1/P sequence per lane, slot counts by direct comparison, the gather through LDS, columns and
+//     ids compacted per column / per id.
+//
+// A chain that does not fit (more particle classes than CLS, more distinct chosen clusters than NDCAP, more reachable clusters
+// than the row table) stops with err = PMDI_S2_REQUEUE and is swept again, from the start, by pmdi_sweep.hip in the same call.
+//
+// Everything here is written against a small lane API (PM2_* macros) so that tests/emu/ can run the same source on the CPU in a
+// lock-step workgroup emulator (test infrastructure; the product build is hipcc for gfx950 only).
+// Compile with -ffp-contract=off.  Reference lines are file:line relative to /root/reference.
+#pragma once
+#include "pmdi_arith.h"
+#include "pmdi_internal.h"
+
+#ifdef PM2_EMU
+#include "../../tests/emu/wavesim.h"
+#include <math.h>
+#define PM2_DEV inline
+#define PM2_HD inline
+#define PM2_SMEM (wavesim::lds_base())
+#define PM2_TID() (wavesim::tid())
+#define PM2_BID() (wavesim::bid())
+#define PM2_BALLOT(p) wavesim::ballot((p), __LINE__)
+#define PM2_SHFL64(v, src) wavesim::shfl64((v), (src), __LINE__)
+#define PM2_WAVE_BARRIER() wavesim::wave_barrier(__LINE__)
+#define PM2_BARRIER() wavesim::block_barrier(__LINE__)
+#define PM2_LDS_BARRIER() wavesim::block_barrier(__LINE__)
+#define PM2_UNI(x) (x)
+#define PM2_CLOCK() (0ll)
+#define PM2_G(T, p) ((T *)(p))
+template <class T> inline T pm2_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
+template <class T> inline T pm2_atomic_min(T *p, T v) { const T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T pm2_atomic_or(T *p, T v) { const T o = *p; *p = o | v; return o; }
+template <class T> inline T pm2_atomic_max(T *p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+inline int pm2_popc64(unsigned long long x) { return __builtin_popcountll(x); }
+inline int pm2_ffs64(unsigned long long x) { return __builtin_ffsll((long long)x); }
+#else
+#define PM2_DEV __device__ __forceinline__
+#define PM2_HD inline __host__ __device__
+extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
+#define PM2_SMEM (pm2_smem_)
+#define PM2_TID() ((int)threadIdx.x)
+#define PM2_BID() ((int)blockIdx.x)
+#define PM2_BALLOT(p) __ballot(p)
+#define PM2_SHFL64(v, src) pm2_shfl64((v), (src))
+#define PM2_WAVE_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define PM2_BARRIER() __syncthreads()
+#define PM2_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PM2_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#define PM2_CLOCK() ((long long)clock64())
+#define PM2_G(T, p) ((__attribute__((address_space(1))) T *)(p))
+__device__ __forceinline__ unsigned long long pm2_shfl64(unsigned long long v, int src)
+{
+    const int lo = __shfl((int)(unsigned)v, src), hi = __shfl((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+}
+template <class T> __device__ __forceinline__ T pm2_atomic_add(T *p, T v) { return atomicAdd(p, v); }
+template <class T> __device__ __forceinline__ T pm2_atomic_min(T *p, T v) { return atomicMin(p, v); }
+template <class T> __device__ __forceinline__ T pm2_atomic_or(T *p, T v) { return atomicOr(p, v); }
+template <class T> __device__ __forceinline__ T pm2_atomic_max(T *p, T v) { return atomicMax(p, v); }
+__device__ __forceinline__ int pm2_popc64(unsigned long long x) { return __popcll(x); }
+__device__ __forceinline__ int pm2_ffs64(unsigned long long x) { return __ffsll((long long)x); }
+#endif
+
+namespace pmdi_s2 {
+
+typedef unsigned long long u64;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+constexpr int T = 256;          // threads of the workgroup (4 waves)
+constexpr int NS = 8;           // cluster cache slots per dataset (registers of the owner wave)
+constexpr int XR = 2;           // extra (uncached) clusters evaluated per round
+constexpr int XCAP = 24;        // uncached reachable clusters per step at most (beyond: requeue)
+constexpr int NR = NS + XR;     // term rows per dataset
+constexpr int CLS = 4;          // particle classes per dataset at most (beyond: requeue)
+constexpr int NDCAP = 256;      // distinct chosen clusters per step at most (beyond: requeue)
+constexpr int KMAX2 = 4;        // datasets (one owner wave each)
+constexpr int NONE8 = 0xFF;
+constexpr unsigned INFU = 0xFFFFFFFFu;
+constexpr int PMDI_S2_REQUEUE = 1;   // err code: sweep this chain again with the general kernel
+
+// per-dataset scalars (ints in LDS)
+enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_ND, DS_NK, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_SLOTFREE, DS_COUNT = 16 };
+// shared scalars
+enum { SC_FAIL = 0, SC_RES, SC_PSTAR, SC_NLEAF, SC_NPROG, SC_JS, SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3, SC_COUNT = 16 };
+
+typedef S2Layout Layout;   // byte offsets into the workgroup's LDS: computed on the host (make_layout), read from the argument block
+
+PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, Layout &L)
+{
+    int o = 0;
+    auto take = [&](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };
+    const int Dp = (Dmax + 1) & ~1;
+    L.Dp = Dp; L.cols_l = cols_l; L.idcap = idcap;
+    L.red = take(64 * 8);
+    L.sc = take(SC_COUNT * 4);
+    L.stat = take(8 * 8);
+    L.wk = take(KMAX2 * 8 * 8);
+    L.leaf_i1 = take(64 * 4); L.leaf_n = take(64 * 4); L.leaf_tot = take(64 * 8); L.leaf_carry = take(64 * 8); L.leaf_prog = take(256);
+    L.xfl = take(KMAX2 * 64);                                   // feature flags per dataset (bytes)
+    // transient region
+    L.tr_tb = 0;
+    L.tr_cdf = NR * Dp * 8 < 128 * 8 ? 128 * 8 : NR * Dp * 8;      // (the tb rows also lend their space to the CDF stage's exchange area and to the prefix's label table)
+    L.tr_stride = (L.tr_cdf + CLS * (N + 2) * 8 + 15) & ~15;
+    // resampling scratch (aliases the transient rows): u table (P doubles; once dead: the per-dataset gather tables scol, mult,
+    // cmap (u16) and scsl (u8): 7 P bytes), slot counts, raw ancestors, ancestors (u16), id histogram (i32)
+    L.rs_jtab = P * 8; L.rs_raw = P * 10; L.rs_anc = P * 12; L.rs_hist = P * 14;
+    const int rs = P * 14 + idcap * 4 + 64;
+    int trb = K * L.tr_stride;
+    if (trb < rs) trb = rs;
+    L.tr_bytes = trb;
+    L.tr = take(trb);
+    // dataset block
+    const int b0 = o;
+    o = 0;
+    L.tab = take(cols_l * N * 2);
+    L.cmask = take(cols_l * 8); L.wmask = take(cols_l * 8); L.cbi = take(cols_l * 4);
+    L.counts = take(idcap * 4); L.cn = take(idcap * 4); L.ncop = take(idcap * 4); L.firstp = take(idcap * 4); L.tgt = take(idcap * 4);
+    L.slotmap = take(idcap);
+    L.ta = take(NS * Dp * 8); L.tax = take(XR * Dp * 8);
+    L.lp = take((NS + XCAP) * 8);
+    L.slot_id = take(NS * 4); L.slot_cn = take(NS * 4); L.slot_g = take(NS * 8);
+    L.clsval = take(CLS * 4); L.clslead = take(CLS * 4); L.leadcol = take(CLS * 4);
+    L.minp = take(CLS * N * 4); L.nidv = take(CLS * N * 4); L.knew = take(CLS * N); L.itemj = take(CLS * N);
+    L.clist = take(NDCAP * 2); L.klist = take(CLS * N * 4); L.kval = take(CLS * N * 4); L.krep = take(CLS * N * 4);
+    L.bmc = take((P / 64 + 1) * 8); L.bmf = take((P / 64 + 1) * 8);
+    L.xid = take(XCAP * 4);
+    L.dsc = take(DS_COUNT * 4);
+    L.ds_stride = o;
+    L.ds0 = b0;
+    L.total = b0 + K * L.ds_stride;
+}
+
+// ---- views ------------------------------------------------------------------------------------------------------------------------
+template <class Tp> PM2_DEV Tp *lds(int off) { return (Tp *)(PM2_SMEM + off); }
+
+struct Arena {   // the chain's arrays of one dataset in global memory (what exceeds the LDS tables; the pool; the history)
+    char *b;
+    const DsetDev *d;
+    PM2_DEV int *tabg() const { return (int *)(b + d->o_particle[0]); }
+    PM2_DEV int *colg() const { return (int *)(b + d->o_col); }
+    PM2_DEV int *pidg() const { return (int *)(b + d->o_pid); }
+    PM2_DEV u64 *cmeta() const { return (u64 *)(b + d->o_cgrp); }
+    PM2_DEV int *newid() const { return (int *)(b + d->o_newid); }
+    PM2_DEV int *counts() const { return (int *)(b + d->o_counts); }
+    PM2_DEV int *cn() const { return (int *)(b + d->o_cn); }
+    PM2_DEV int *ncop() const { return (int *)(b + d->o_ncop); }
+    PM2_DEV int *firstp() const { return (int *)(b + d->o_firstc); }
+    PM2_DEV int *tgt() const { return (int *)(b + d->o_lp); }
+    PM2_DEV double *sb() const { return (double *)(b + d->o_sb); }
+    PM2_DEV u8 *sstar() const { return (u8 *)(b + d->o_sstar); }
+};
+
+struct DV {      // view of one dataset: LDS block + arena
+    int base;            // LDS offset of the dataset block
+    int trb;             // LDS offset of its transient rows
+    int N, P, D, Dp, cols_l, idcap;
+    const Layout *lay;
+    Arena ar;
+    PM2_DEV int *dsc() const { return lds<int>(base + lay->dsc); }
+    // particle[label, column]: the distinct columns of particle[:, :, k]
+    PM2_DEV int tab_get(int c, int nn) const { return c < cols_l ? (int)lds<u16>(base + lay->tab)[c * N + nn] : PM2_G(int, ar.tabg())[(size_t)c * N + nn]; }
+    PM2_DEV void tab_set(int c, int nn, int v) const
+    {
+        if (c < cols_l) lds<u16>(base + lay->tab)[c * N + nn] = (u16)v; else PM2_G(int, ar.tabg())[(size_t)c * N + nn] = v;
+    }
+    // per-column tables
+    PM2_DEV u64 *cmask_p(int c) const { return c < cols_l ? lds<u64>(base + lay->cmask) + c : ar.cmeta() + c; }
+    PM2_DEV u64 *wmask_p(int c) const { return c < cols_l ? lds<u64>(base + lay->wmask) + c : ar.cmeta() + P + c; }
+    PM2_DEV int *cbi_p(int c) const { return c < cols_l ? lds<int>(base + lay->cbi) + c : (int *)(ar.cmeta() + 2 * (size_t)P) + c; }
+    // per-id tables
+    PM2_DEV int *counts_p(int id) const { return id < idcap ? lds<int>(base + lay->counts) + id : ar.counts() + id; }
+    PM2_DEV int *cn_p(int id) const { return id < idcap ? lds<int>(base + lay->cn) + id : ar.cn() + id; }
+    PM2_DEV int *ncop_p(int id) const { return id < idcap ? lds<int>(base + lay->ncop) + id : ar.ncop() + id; }
+    PM2_DEV int *firstp_p(int id) const { return id < idcap ? lds<int>(base + lay->firstp) + id : ar.firstp() + id; }
+    PM2_DEV int *tgt_p(int id) const { return id < idcap ? lds<int>(base + lay->tgt) + id : ar.tgt() + id; }
+    PM2_DEV int slot_of(int id) const { return id < idcap ? (int)lds<u8>(base + lay->slotmap)[id] : NONE8; }
+    PM2_DEV void slot_set(int id, int s) const { if (id < idcap) lds<u8>(base + lay->slotmap)[id] = (u8)s; }
+    PM2_DEV double *ta_row(int j) const { return j < NS ? lds<double>(base + lay->ta) + j * Dp : lds<double>(base + lay->tax) + (j - NS) * Dp; }
+    PM2_DEV double *tb_row(int j) const { return lds<double>(trb + lay->tr_tb) + j * Dp; }
+    PM2_DEV double *cdf_row(int r) const { return lds<double>(trb + lay->tr_cdf) + r * (N + 2); }
+    PM2_DEV double *lp() const { return lds<double>(base + lay->lp); }
+};
+
+PM2_DEV double shfl_d(double v, int src)
+{
+    union { double d; u64 u; } a, b;
+    a.d = v;
+    b.u = PM2_SHFL64(a.u, src);
+    return b.d;
+}
+PM2_DEV int shfl_i(int v, int src) { return (int)(unsigned)PM2_SHFL64((u64)(unsigned)v, src); }
+// the value of lane `src` (wave-uniform): v_readlane on the device
+PM2_DEV int readlane_i(int v, int src) { return shfl_i(v, src); }
+
+PM2_DEV double wave_max_d(double v)
+{
+    const int lane = PM2_TID() & 63;
+    for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = (t > v) ? t : v; }
+    return v;
+}
+PM2_DEV double wave_sum_d(double v)
+{
+    const int lane = PM2_TID() & 63;
+    for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = v + t; }
+    return v;
+}
+// exclusive prefix sum of an int over the wave, and the total
+PM2_DEV int wave_excl_scan_i(int v, int &total)
+{
+    const int lane = PM2_TID() & 63;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = shfl_i(inc, lane - o); if (lane >= o) inc += t; }
+    total = shfl_i(inc, 63);
+    return inc - v;
+}
+// set bits strictly below bit p of a bitmap of 64-bit words
+PM2_DEV int popc_below64(const u64 *bm, int p)
+{
+    int n = 0;
+    const int w = p >> 6;
+    for (int i = 0; i < w; ++i) n += pm2_popc64(bm[i]);
+    return n + pm2_popc64(bm[w] & ((1ull << (p & 63)) - 1ull));
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+template <int K, int PPL>
+struct Sweep2 {
+    // ---- per-lane state ----
+    double lw[PPL];
+    int col[K][PPL], csl[K][PPL];
+    double c_mu[NS], c_lam[NS], c_sg[NS], c_bt[NS];     // owner wave: the cluster cache of its dataset, lane = feature
+    // ---- uniform ----
+    const SweepArgs *ap;
+    int tid, lane, wave, chain;
+    int N, P;
+    unsigned long long seed;
+    unsigned iter;
+    long long n, n1;
+
+#define L (ap->s2)
+    PM2_DEV DV view(int k) const
+    {
+        DV v;
+        v.base = L.ds0 + k * L.ds_stride; v.trb = L.tr + k * L.tr_stride;
+        v.N = N; v.P = P; v.D = ap->ds[k].D; v.Dp = L.Dp; v.cols_l = L.cols_l; v.idcap = L.idcap; v.lay = &ap->s2;
+        v.ar.d = &ap->ds[k];
+        v.ar.b = ap->ds[k].arena + (size_t)chain * ap->ds[k].stride;
+        return v;
+    }
+    PM2_DEV int *sc() const { return lds<int>(L.sc); }
+    PM2_DEV long long *stat() const { return lds<long long>(L.stat); }
+    PM2_DEV long long *wk(int k) const { return lds<long long>(L.wk) + k * 8; }
+    PM2_DEV const u8 *flk(int k) const { return lds<u8>(L.xfl) + k * 64; }
+
+    // ---- cluster cache (owner wave) -------------------------------------------------------------------------------------------
+    // load the statistics of cluster `id` into slot s0 (uniform) of the owner wave: lane = feature
+    PM2_DEV void cache_fill(const DV &v, int k, int s0, double sg, double bt, int cnv)
+    {
+        double mu, lam;
+        pmdi_arith::gauss_ml(cnv, sg, bt, mu, lam);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (s == s0) { c_sg[s] = sg; c_bt[s] = bt; c_mu[s] = mu; c_lam[s] = lam; }
+        if (lane < v.D) v.ta_row(s0)[lane] = 0.5 * log(lam / ((double)cnv + 1.0));            // gaussian_cluster.jl:45
+        if (lane == 0) {
+            lds<int>(v.base + L.slot_cn)[s0] = cnv;
+            lds<double>(v.base + L.slot_g)[s0] = (double)v.dsc()[DS_NFLAG] * PM2_G(const double, ap->ds[k].gtab)[cnv];   // :38-40
+        }
+    }
+
+    // ---- reset (src/pmdi.jl:165-171) and known prefix (:188-207), by the owner wave of dataset k ----------------------------------
+    PM2_DEV void prefix(int k)
+    {
+        const DV v = view(k);
+        const DsetDev &d = ap->ds[k];
+        const int D = d.D;
+        int *dsc = v.dsc();
+        const int *s_in = PM2_G(const int, ap->s_in) + ((size_t)chain * K + k) * n;
+        const int *order = PM2_G(const int, ap->order) + (size_t)chain * n;
+        const u8 *flags = ap->flags ? PM2_G(const u8, ap->flags) + (size_t)chain * ap->sumD + d.flag_off : (const u8 *)nullptr;
+        u8 *fl = lds<u8>(L.xfl) + k * 64;
+        int *lab = lds<int>(v.trb + L.tr_tb);               // [0,64) first position, [64,128) id, [128,192) count (the tb rows are idle)
+        for (int e = lane; e < v.idcap; e += 64) {
+            lds<int>(v.base + L.counts)[e] = 0; lds<int>(v.base + L.cn)[e] = 0; lds<int>(v.base + L.ncop)[e] = 0;
+            lds<int>(v.base + L.firstp)[e] = 0x7fffffff; lds<int>(v.base + L.tgt)[e] = 0; lds<u8>(v.base + L.slotmap)[e] = NONE8;
+        }
+        for (int e = lane; e < v.cols_l; e += 64) { lds<u64>(v.base + L.cmask)[e] = 0; lds<u64>(v.base + L.wmask)[e] = 0; lds<int>(v.base + L.cbi)[e] = 0; }
+        for (int e = lane; e < CLS * N; e += 64) lds<unsigned>(v.base + L.minp)[e] = INFU;
+        for (int e = lane; e < P / 64 + 1; e += 64) { lds<u64>(v.base + L.bmc)[e] = 0; lds<u64>(v.base + L.bmf)[e] = 0; }
+        for (int e = lane; e < NS; e += 64) lds<int>(v.base + L.slot_id)[e] = 0;
+        if (lane < 64) { lab[lane] = 0x7fffffff; lab[64 + lane] = 0; lab[128 + lane] = 0; fl[lane] = (lane < D) ? (flags ? flags[lane] : (u8)1) : (u8)0; }
+        // what lives in the arena: new_id (:167), the per-id scratch beyond idcap, the column tables beyond cols_l
+        {
+            int *nid = PM2_G(int, v.ar.newid());
+            for (int e = lane; e < N * P; e += 64) nid[e] = 0;
+            int *g1 = PM2_G(int, v.ar.ncop()), *g2 = PM2_G(int, v.ar.firstp()), *g3 = PM2_G(int, v.ar.counts());
+            for (int e = v.idcap + lane; e <= ap->cap; e += 64) { g1[e] = 0; g2[e] = 0x7fffffff; g3[e] = 0; }
+            u64 *cm = PM2_G(u64, v.ar.cmeta());
+            for (int e = v.cols_l + lane; e < P; e += 64) { cm[e] = 0; cm[P + e] = 0; }
+        }
+        PM2_WAVE_BARRIER();
+        // unique(s[order_obs[1:n1-1], k]) in first-appearance order (:192)
+        for (long long j = lane; j < n1 - 1; j += 64) {
+            const int u = s_in[order[j]];
+            pm2_atomic_min(&lab[u], (int)j);
+            pm2_atomic_add(&lab[128 + u], 1);
+        }
+        PM2_WAVE_BARRIER();
+        int nu = 0;
+        for (int u = 0; u < N; ++u) nu += (lab[u] != 0x7fffffff) ? 1 : 0;
+        if (lane < N) {
+            const int fp = lab[lane];
+            int id = 1;
+            if (fp != 0x7fffffff) {
+                int r = 0;
+                for (int u = 0; u < N; ++u) r += (lab[u] < fp) ? 1 : 0;
+                id = 2 + r;                                    // cluster id of label u (:197)
+                lab[64 + lane] = id;
+                *v.counts_p(id) = P;
+                *v.cn_p(id) = lab[128 + lane];
+            }
+            v.tab_set(0, lane, id);                            // particle[u, :, k] .= id (:195): one column
+        }
+        if (lane == 0) { *v.counts_p(1) = P * N - nu * P; *v.cn_p(1) = 0; }
+        PM2_WAVE_BARRIER();
+        // fresh clusters and the first n1-1 shuffled observations joining their previous cluster, sequentially in shuffled
+        // order (:189,:194,:201-206): lane = feature, one label after the other
+        {
+            double *sb = PM2_G(double, v.ar.sb());
+            const double *xf = PM2_G(const double, d.xf);
+            if (lane < D) { sb[((size_t)1 * D + lane) * 2] = 0.0; sb[((size_t)1 * D + lane) * 2 + 1] = 0.5; }
+            for (int u = 0; u < N; ++u) {
+                const int id = lab[64 + u];
+                if (!id) continue;
+                double sg = 0.0, bt = 0.5;
+                if (lane < D && fl[lane]) {
+                    int c = 0;
+                    for (long long j = 0; j < n1 - 1; ++j) {
+                        const int i = order[j];
+                        if (s_in[i] != u) continue;
+                        ++c;
+                        pmdi_arith::gauss_add_sb(xf[(size_t)i * D + lane], c, sg, bt);
+                    }
+                }
+                if (lane < D) { sb[((size_t)id * D + lane) * 2] = sg; sb[((size_t)id * D + lane) * 2 + 1] = bt; }
+            }
+        }
+        if (lane == 0) {
+            int nf = 0;
+            for (int q = 0; q < D; ++q) nf += fl[q];
+            dsc[DS_NFLAG] = nf; dsc[DS_MAXID] = nu + 1; dsc[DS_NCLS] = 1; dsc[DS_NCOL] = 1; dsc[DS_ND] = 0; dsc[DS_NK] = 0; dsc[DS_NX] = 0;
+            lds<int>(v.base + L.clsval)[0] = 1; lds<int>(v.base + L.clslead)[0] = 0; lds<int>(v.base + L.leadcol)[0] = 0;
+        }
+        PM2_WAVE_BARRIER();
+    }
+
+    // ---- phase A (owner wave of dataset k): log-predictives of the clusters the class leaders can reach (src/pmdi.jl:218-220,:232),
+    //      the mutation CDF of every particle class (:231-248) -------------------------------------------------------------------------
+    PM2_DEV void phase_a(int k, double x, int i_obs, long long pos)
+    {
+        const DV v = view(k);
+        const DsetDev &d = ap->ds[k];
+        const int D = d.D;
+        int *dsc = v.dsc();
+        const int ncls = PM2_UNI(dsc[DS_NCLS]);
+        const u8 *fl = flk(k);
+        const bool on = lane < D && fl[lane];
+        u8 *itemj = lds<u8>(v.base + L.itemj);
+        int *slot_id = lds<int>(v.base + L.slot_id);
+        int *xid = lds<int>(v.base + L.xid);
+        // -- A1: the clusters the class leaders' columns hold; their cache slots (stable while a cluster stays reachable)
+        unsigned needmask = 0;
+        int nx = 0;
+        int item_id[CLS];
+        int nid_pref[CLS];
+#pragma unroll
+        for (int r = 0; r < CLS; ++r) {
+            item_id[r] = 0; nid_pref[r] = 0;
+            if (r < ncls) {
+                const int lc = lds<int>(v.base + L.leadcol)[r];
+#ifdef PM2_EMU
+                if (lc < 0 || lc >= P) { fprintf(stderr, "phase_a: pos %lld k %d r %d ncls %d leadcol %d (lane %d)\n", pos, k, r, ncls, lc, lane); abort(); }
+#endif
+                const int id = (lane < N) ? v.tab_get(lc, lane) : 0;
+                item_id[r] = id;
+                const int s = (lane < N) ? v.slot_of(id) : NONE8;
+                for (int sb_ = 0; sb_ < NS; ++sb_) if (PM2_BALLOT(s == sb_)) needmask |= 1u << sb_;
+                // new_id of the (class, label) keys, fetched now and needed after the draw (:266)
+                if (lane < N && ap->q1 == 0) nid_pref[r] = PM2_G(const int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + lane];
+            }
+        }
+        int nneed_new = 0;
+#pragma unroll
+        for (int r = 0; r < CLS; ++r) {
+            if (r < ncls) {
+                const int id = item_id[r];
+                int j = (lane < N) ? v.slot_of(id) : 0;
+                bool missing = lane < N && j == NONE8;
+                if (missing)                                   // an uncached cluster another class already asked for
+                    for (int e = 0; e < nx; ++e) if (xid[e] == id) { j = NS + e; missing = false; }
+                u64 m;
+                while ((m = PM2_BALLOT(missing)) != 0) {
+                    const int l0 = pm2_ffs64(m) - 1;
+                    const int id0 = readlane_i(id, l0);
+                    const unsigned freem = ~needmask & ((1u << NS) - 1u);
+                    int row;
+                    if (id0 < v.idcap && freem) {
+                        const int s0 = __builtin_ffs((int)freem) - 1;
+                        if (lane == 0) {
+                            const int old = slot_id[s0];
+                            if (old) v.slot_set(old, NONE8);
+                            slot_id[s0] = id0;
+                            v.slot_set(id0, s0);
+                        }
+                        needmask |= 1u << s0;
+                        const double *sb = PM2_G(const double, v.ar.sb());
+                        double sg = 0.0, bt = 0.5;
+                        if (lane < D) { sg = sb[((size_t)id0 * D + lane) * 2]; bt = sb[((size_t)id0 * D + lane) * 2 + 1]; }
+                        cache_fill(v, k, s0, sg, bt, *v.cn_p(id0));
+                        row = s0;
+                    } else {
+                        if (nx >= XCAP) { if (lane == 0) sc()[SC_FAIL] = 2; nx = XCAP - 1; }          // too many uncached reachable clusters
+                        if (lane == 0) xid[nx] = id0;
+                        row = NS + nx;
+                        nx += 1;
+                    }
+                    nneed_new += 1;
+                    if (missing && id == id0) { j = row; missing = false; }
+                    PM2_WAVE_BARRIER();
+                }
+                if (lane < N) { itemj[r * N + lane] = (u8)j; lds<int>(v.base + L.nidv)[r * N + lane] = nid_pref[r]; }
+            }
+        }
+        (void)nneed_new;
+        // slots that are no longer reachable are given up (their ids leave the map): the cache holds what the step reads
+        {
+            const unsigned dead = ~needmask & ((1u << NS) - 1u);
+            if (lane < NS && ((dead >> lane) & 1u)) { const int old = slot_id[lane]; if (old) { v.slot_set(old, NONE8); slot_id[lane] = 0; } }
+        }
+        const int nneed = __builtin_popcount(needmask) + nx;
+        if (lane == 0) { dsc[DS_NX] = nx; dsc[DS_NNEED] = nneed; }
+        PM2_WAVE_BARRIER();
+        // -- A2: the per-feature terms: cached clusters need one log per feature (gaussian_cluster.jl:46-48), lane = feature
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if ((needmask >> s) & 1u) {
+                const double nd_ = (double)lds<int>(v.base + L.slot_cn)[s];
+                const double dd = x - c_mu[s];
+                const double tb = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * c_lam[s]);
+                if (lane < D) v.tb_row(s)[lane] = tb;
+            }
+        }
+        // -- A3: ordered sums, one lane per cluster row (calc_logprob's loop, gaussian_cluster.jl:41-50, same terms, same order)
+        double *lp = v.lp();
+        PM2_WAVE_BARRIER();
+        if (lane < NS && ((needmask >> lane) & 1u)) {
+            const double *ta = v.ta_row(lane), *tb = v.tb_row(lane);
+            double out = lds<double>(v.base + L.slot_g)[lane];
+            for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
+            lp[lane] = out;
+        }
+        // uncached reachable clusters, XR per round: statistics from the pool, both terms on the fly
+        for (int e0 = 0; e0 < nx; e0 += XR) {
+            PM2_WAVE_BARRIER();
+            for (int e = e0; e < nx && e < e0 + XR; ++e) {
+                const int id = xid[e];
+                const int cnv = *v.cn_p(id);
+                const double *sb = PM2_G(const double, v.ar.sb());
+                if (on) {
+                    double mu, lam;
+                    pmdi_arith::gauss_ml(cnv, sb[((size_t)id * D + lane) * 2], sb[((size_t)id * D + lane) * 2 + 1], mu, lam);
+                    const double nd_ = (double)cnv, dd = x - mu;
+                    v.ta_row(NS + e - e0)[lane] = 0.5 * log(lam / (nd_ + 1.0));
+                    v.tb_row(NS + e - e0)[lane] = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
+                }
+            }
+            PM2_WAVE_BARRIER();
+            if (lane < XR && e0 + lane < nx) {
+                const int id = xid[e0 + lane];
+                const double *ta = v.ta_row(NS + lane), *tb = v.tb_row(NS + lane);
+                double out = (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[*v.cn_p(id)];
+                for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
+                lp[NS + e0 + lane] = out;
+            }
+        }
+        PM2_WAVE_BARRIER();
+        // -- A4: mutation CDF per particle class (:231-248): lanes = (class, label); max / cumsum / normalise through a per-wave
+        // exchange area.  The cumsum follows Julia's accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]) (n < 128).
+        {
+            const double *pik = PM2_G(const double, ap->Pi) + ((size_t)chain * K + k) * N;
+            double *wv = lds<double>(v.trb + L.tr_tb);          // (the tb rows are dead: the sums are done)
+            const int G = 64 / N;
+            const int g = lane / N, nn = lane - g * N;
+            const int gbase = (g < G) ? g * N : 0;
+            for (int r0 = 0; r0 < ncls; r0 += G) {
+                const int r = r0 + g;
+                const bool valid = (g < G) && (r < ncls);
+                double val = 0.0;
+                if (valid) val = lp[itemj[r * N + nn]];
+                wv[lane] = val;
+                PM2_WAVE_BARRIER();
+                double m = val;
+                for (int j = 0; j < N; ++j) { const double t = wv[gbase + j]; m = (t > m) ? t : m; }
+                double e = val - m;
+                e = exp(e);
+                e = e * (valid ? pik[nn] : 0.0);
+                wv[64 + lane] = e;
+                PM2_WAVE_BARRIER();
+                const double e0v = wv[64 + gbase];
+                double s_ = 0.0;
+                for (int j = 1; j < N; ++j) { const double t = wv[64 + gbase + j]; if (j <= nn) s_ = (j == 1) ? t : s_ + t; }
+                const double c = (nn == 0) ? e : e0v + s_;
+                PM2_WAVE_BARRIER();
+                wv[lane] = c;
+                PM2_WAVE_BARRIER();
+                const double fN = wv[gbase + N - 1];
+                const double cd = c / fN;
+                // one-hot to working precision?  every uniform is an odd multiple of 2^-53, so a label whose CDF is < 2^-53 is never
+                // chosen and one whose CDF is 1.0 always stops the search: the draw (:252-260) is then the same label for every u
+                const u64 m_one = PM2_BALLOT(valid && (cd == 1.0 || nn == N - 1));
+                const u64 m_tiny = PM2_BALLOT(valid && cd < 0x1p-53);
+                if (valid) {
+                    double *row = v.cdf_row(r);
+                    row[nn] = cd;
+                    if (nn == N - 1) {
+                        row[N] = log(fN) + m;
+                        const u64 grp = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << gbase);
+                        const int nstar = pm2_ffs64((m_one & grp) >> gbase) - 1;
+                        const u64 below = (nstar == 0) ? 0ull : ((1ull << nstar) - 1ull);
+                        const bool onehot = (((m_tiny & grp) >> gbase) & below) == below;
+                        row[N + 1] = onehot ? (double)nstar : -1.0;
+                    }
+                }
+                PM2_WAVE_BARRIER();
+            }
+        }
+#ifdef PM2_EMU
+        if (getenv("PM2_DEBUG") && lane == 0 && pos - (n1 - 1) <= atoi(getenv("PM2_DEBUG"))) {
+            for (int r = 0; r < ncls; ++r) {
+                fprintf(stderr, "E pos %lld k %d class %d leader %d inc %.17g ids:", pos, k, lds<int>(v.base + L.clsval)[r], lds<int>(v.base + L.clslead)[r], v.cdf_row(r)[N]);
+                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %d", v.tab_get(lds<int>(v.base + L.leadcol)[r], nn));
+                fprintf(stderr, " lp:");
+                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", lp[itemj[r * N + nn]]);
+                fprintf(stderr, " cdf:");
+                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", v.cdf_row(r)[nn]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
+        if (lane == 0) dsc[DS_NS0] = PM2_G(const int, ap->s_in)[((size_t)chain * K + k) * n + i_obs];     // reference trajectory (:262)
+        (void)pos;
+    }
+
+    // ---- phase C (owner wave): what the draws of this step mean for the tables -- copy-on-write decisions (:275-299), class ids
+    //      (:266-272), column splits (:301-308), sufficient statistics (:297,:300) ------------------------------------------------------
+    PM2_DEV bool phase_c(int k, double x, long long pos)
+    {
+        const DV v = view(k);
+        const DsetDev &d = ap->ds[k];
+        const int D = d.D;
+        int *dsc = v.dsc();
+        const u8 *fl = flk(k);
+        const int nd = PM2_UNI(dsc[DS_ND]), nk = PM2_UNI(dsc[DS_NK]);
+        const int maxid = PM2_UNI(dsc[DS_MAXID]), ncol = PM2_UNI(dsc[DS_NCOL]), ncls = PM2_UNI(dsc[DS_NCLS]);
+        u16 *clist = lds<u16>(v.base + L.clist);
+        int *klist = lds<int>(v.base + L.klist), *kval = lds<int>(v.base + L.kval), *krep = lds<int>(v.base + L.krep);
+        unsigned *minp = lds<unsigned>(v.base + L.minp);
+        u64 *bmc = lds<u64>(v.base + L.bmc), *bmf = lds<u64>(v.base + L.bmf);
+        if (nd > NDCAP) { if (lane == 0) sc()[SC_FAIL] = 3; return false; }          // too many distinct chosen clusters
+        // -- C1: clone or in place (:286-299): a chosen cluster all of whose references were chosen is updated in place
+        for (int e0 = 0; e0 < nd; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < nd) {
+                const int c = clist[e];
+                if (*v.ncop_p(c) != *v.counts_p(c)) { const int fp = *v.firstp_p(c); pm2_atomic_or(&bmc[fp >> 6], 1ull << (fp & 63)); }
+            }
+        }
+        PM2_WAVE_BARRIER();
+        int nclone = 0;
+        for (int w = 0; w < P / 64; ++w) nclone += pm2_popc64(bmc[w]);
+        if (maxid + nclone > ap->cap) { if (lane == 0) sc()[SC_FAIL] = 1; return false; }      // PMDI_E_POOL
+        for (int e0 = 0; e0 < nd; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < nd) {
+                const int c = clist[e];
+                const int ncp = *v.ncop_p(c), fp = *v.firstp_p(c);
+                const bool needs = ncp != *v.counts_p(c);
+                const int t = needs ? maxid + 1 + popc_below64(bmc, fp) : c;       // first-appearance order over the particles (:290-292)
+                *v.tgt_p(c) = t;
+                const int nnew = *v.cn_p(c) + 1;
+                if (needs) { *v.counts_p(c) -= ncp; *v.counts_p(t) = ncp; }         // (:293-294)
+                *v.cn_p(t) = nnew;
+            }
+        }
+        // -- C2: class ids of the next step (:266-272): a (class, label) key met for the first time in this Gibbs iteration gets
+        // the next id in particle order (curr_id restarts at 0 every step: Q1), others reuse the id stored under the key
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < nk) {
+                const int key = klist[j];
+                const int v0 = (ap->q1 == 1) ? 0 : lds<int>(v.base + L.nidv)[key];
+                if (v0 <= 0) { const int pf = (int)(minp[key] >> 16); pm2_atomic_or(&bmf[pf >> 6], 1ull << (pf & 63)); }
+            }
+        }
+        PM2_WAVE_BARRIER();
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < nk) {
+                const int key = klist[j];
+                const int r = key / N, ns = key - r * N;
+                int v0 = (ap->q1 == 1) ? 0 : lds<int>(v.base + L.nidv)[key];
+                if (v0 <= 0) {
+                    v0 = 1 + popc_below64(bmf, (int)(minp[key] >> 16));            // curr_id += 1 (:267-269)
+                    if (ap->q1 == 0) PM2_G(int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + ns] = v0;
+                }
+                kval[j] = v0;
+            }
+        }
+        PM2_WAVE_BARRIER();
+        // classes of the next step: one per distinct value, leader = lowest first particle, slots in leader order
+        int nrep = 0;
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+            const int j = j0 + lane;
+            bool rep = false;
+            if (j < nk) {
+                const int v0 = kval[j];
+                const unsigned mp = minp[klist[j]];
+                rep = true;
+                for (int j2 = 0; j2 < nk; ++j2) if (kval[j2] == v0 && minp[klist[j2]] < mp) rep = false;
+                krep[j] = rep ? 1 : 0;
+            }
+            nrep += pm2_popc64(PM2_BALLOT(rep));
+        }
+        if (nrep > CLS) { if (lane == 0) sc()[SC_FAIL] = 4; return false; }           // too many particle classes
+        PM2_WAVE_BARRIER();
+        // -- C3: column splits (:301-308): particles of one column that chose the same label move together; the group whose chosen
+        // cluster was cloned takes a copy of the column with that entry replaced -- or the column itself when nobody stays behind
+        int ncol_new = ncol;
+        for (int c0 = 0; c0 < ncol; c0 += 64) {
+            const int cc = c0 + lane;
+            u64 wm = 0;
+            bool keeper = false;
+            if (cc < ncol) {
+                u64 cm = *v.cmask_p(cc);
+                *v.cmask_p(cc) = 0;
+                while (cm) {
+                    const int ns = pm2_ffs64(cm) - 1;
+                    cm &= cm - 1;
+                    const int c = v.tab_get(cc, ns);
+                    if (*v.tgt_p(c) != c) wm |= 1ull << ns; else keeper = true;
+                }
+            }
+            const int nw = pm2_popc64(wm);
+            const int nnew = keeper ? nw : (nw > 0 ? nw - 1 : 0);
+            const int inpl = (!keeper && nw > 0) ? pm2_ffs64(wm) - 1 : -1;
+            int tot;
+            const int base = ncol_new + wave_excl_scan_i(nnew, tot);
+            if (cc < ncol) { *v.wmask_p(cc) = wm; *v.cbi_p(cc) = (base << 8) | (inpl + 1); }
+            // the copies, then the in-place entry (the copies read the column as it was)
+            u64 m;
+            bool todo = wm != 0;
+            while ((m = PM2_BALLOT(todo)) != 0) {
+                const int l0 = pm2_ffs64(m) - 1;
+                const int cs = c0 + l0;
+                union { u64 u; double dd; } uw; uw.u = wm;
+                union { u64 u; double dd; } ur; ur.dd = shfl_d(uw.dd, l0);
+                u64 wm0 = ur.u;
+                const int base0 = readlane_i(base, l0), inpl0 = readlane_i(inpl, l0);
+                int rnk = 0;
+                while (wm0) {
+                    const int ns = pm2_ffs64(wm0) - 1;
+                    wm0 &= wm0 - 1;
+                    if (ns != inpl0) {
+                        const int newc = base0 + rnk - (inpl0 >= 0 ? 1 : 0);
+                        const int t = *v.tgt_p(v.tab_get(cs, ns));
+                        if (lane < N) v.tab_set(newc, lane, lane == ns ? t : v.tab_get(cs, lane));
+                    }
+                    rnk += 1;
+                }
+                PM2_WAVE_BARRIER();                            // (the copies have read the column as it was)
+                if (inpl0 >= 0 && lane == 0) v.tab_set(cs, inpl0, *v.tgt_p(v.tab_get(cs, inpl0)));
+                if (lane == l0) todo = false;
+            }
+            ncol_new += tot;
+        }
+        PM2_WAVE_BARRIER();
+        // the class list of the next step and every key's class slot; the leader's column after the split
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < nk) {
+                const int key = klist[j];
+                const int v0 = kval[j];
+                int jr = j;
+                for (int j2 = 0; j2 < nk; ++j2) if (krep[j2] && kval[j2] == v0) jr = j2;
+                const unsigned mpr = minp[klist[jr]];
+                int slot = 0;
+                for (int j2 = 0; j2 < nk; ++j2) if (krep[j2] && minp[klist[j2]] < mpr) ++slot;
+                lds<u8>(v.base + L.knew)[key] = (u8)slot;
+                if (krep[j]) {
+                    const int pl = (int)(mpr >> 16), cl = (int)(mpr & 0xffffu);
+                    const int ns = key - (key / N) * N;
+                    const u64 wm = *v.wmask_p(cl);
+                    int newc = cl;
+                    if ((wm >> ns) & 1ull) {
+                        const int bi = *v.cbi_p(cl);
+                        const int inpl = (bi & 0xff) - 1, base = bi >> 8;
+                        const int rnk = pm2_popc64(wm & ((1ull << ns) - 1ull));
+                        newc = (inpl >= 0) ? (ns == inpl ? cl : base + rnk - 1) : base + rnk;
+                    }
+                    lds<int>(v.base + L.clsval)[slot] = v0; lds<int>(v.base + L.clslead)[slot] = pl; lds<int>(v.base + L.leadcol)[slot] = newc;
+                }
+            }
+        }
+        PM2_WAVE_BARRIER();
+#ifdef PM2_EMU
+        if (getenv("PM2_DEBUG") && lane == 0) {
+            fprintf(stderr, "C pos %lld k %d: nd %d nk %d nrep %d nclone %d ncol %d->%d maxid %d |", pos, k, nd, nk, nrep, nclone, ncol, ncol_new, maxid);
+            for (int j = 0; j < nk; ++j) fprintf(stderr, " key %d val %d rep %d p %u col %u;", klist[j], kval[j], krep[j], minp[klist[j]] >> 16, minp[klist[j]] & 0xffff);
+            for (int r = 0; r < nrep; ++r) fprintf(stderr, " cls[%d]=(%d,%d,%d)", r, lds<int>(v.base + L.clsval)[r], lds<int>(v.base + L.clslead)[r], lds<int>(v.base + L.leadcol)[r]);
+            fprintf(stderr, "\n");
+        }
+#endif
+        // -- C4: deepcopy + cluster_add! of every distinct chosen cluster (:297,:300), lane = feature; a cached cluster is updated in
+        // its registers (and written through to the pool), the others go through the pool
+        {
+            double *sb = PM2_G(double, v.ar.sb());
+            for (int e = 0; e < nd; ++e) {
+                const int c = clist[e];
+                const int t = *v.tgt_p(c);
+                const int nnew = *v.cn_p(t);
+                const int s0 = v.slot_of(c);
+                double sg = 0.0, bt = 0.5;
+                if (s0 != NONE8) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) if (s == s0) { sg = c_sg[s]; bt = c_bt[s]; }
+                } else if (lane < D) {
+                    sg = sb[((size_t)c * D + lane) * 2]; bt = sb[((size_t)c * D + lane) * 2 + 1];
+                }
+                const bool on = lane < D && fl[lane];
+                if (on) pmdi_arith::gauss_add_sb(x, nnew, sg, bt);
+                if (lane < D && (on || t != c)) { sb[((size_t)t * D + lane) * 2] = sg; sb[((size_t)t * D + lane) * 2 + 1] = bt; }
+                if (s0 != NONE8 && t == c) cache_fill(v, k, s0, sg, bt, nnew);
+            }
+        }
+        // -- C5: the step's scratch back to its idle state; counters
+        PM2_WAVE_BARRIER();
+        for (int e0 = 0; e0 < nd; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < nd) { const int c = clist[e]; *v.ncop_p(c) = 0; *v.firstp_p(c) = 0x7fffffff; }
+        }
+        for (int j0 = 0; j0 < nk; j0 += 64) { const int j = j0 + lane; if (j < nk) minp[klist[j]] = INFU; }
+        for (int w = lane; w < P / 64 + 1; w += 64) { bmc[w] = 0; bmf[w] = 0; }
+        if (lane == 0) {
+            long long *st = stat();
+            // (the K owner waves add to the shared counters one after the other in phase order: atomics keep them exact)
+            pm2_atomic_add((u64 *)&st[0], (u64)maxid);                   // src/__pmdi.jl:187
+            pm2_atomic_add((u64 *)&st[4], (u64)ncls);
+            pm2_atomic_add((u64 *)&st[2], (u64)nclone);
+            pm2_atomic_add((u64 *)&st[5], (u64)1);
+            pm2_atomic_max((u64 *)&st[3], (u64)(maxid + nclone));        // max_id: after the copy-on-write, before any renumbering
+            long long *w_ = wk(k);
+            w_[WK_EVAL] += dsc[DS_NNEED]; w_[WK_UPD] += nd; w_[WK_CLONE] += nclone; w_[WK_SPLITS] += ncol_new - ncol;
+            dsc[DS_MAXID] = maxid + nclone; dsc[DS_NCLS] = nrep; dsc[DS_NCOL] = ncol_new; dsc[DS_ND] = 0; dsc[DS_NK] = 0; dsc[DS_NCLONE] = nclone;
+        }
+        (void)pos;
+        return true;
+    }
+
+    // ---- the census of one particle's draw, aggregated over the lanes of the wave that drew the same (class, column, label) -------
+    PM2_DEV void census(const DV &v, int r, int cl, int ns, int c, int p)
+    {
+        int *dsc = v.dsc();
+        const int key3 = (r * P + cl) * N + ns;
+        u64 rem = ~0ull;
+        while (rem) {
+            const int l0 = pm2_ffs64(rem) - 1;
+            const int k0 = readlane_i(key3, l0);
+            const u64 m = PM2_BALLOT(key3 == k0);
+            if (lane == l0) {
+                const int cnt = pm2_popc64(m);
+                // chosen cluster: copies and first particle (:279)
+                const int old = pm2_atomic_add(v.ncop_p(c), cnt);
+                pm2_atomic_min(v.firstp_p(c), p);
+                if (old == 0) { const int idx = pm2_atomic_add(&dsc[DS_ND], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[idx] = (u16)c; }
+                // (class, label) key: first particle, with its column
+                const int key = r * N + ns;
+                const unsigned oldk = pm2_atomic_min(&lds<unsigned>(v.base + L.minp)[key], ((unsigned)p << 16) | (unsigned)cl);
+                if (oldk == INFU) { const int idx = pm2_atomic_add(&dsc[DS_NK], 1); lds<int>(v.base + L.klist)[idx] = key; }
+                // labels chosen on this column
+                pm2_atomic_or(v.cmask_p(cl), 1ull << ns);
+            }
+            rem &= ~m;
+        }
+    }
+
+    // ---- Julia's accumulate_pairwise! over the P weights held PPL per lane (src/misc.jl:29): returns c[p] for the lane's particles --
+    // leaves: [1, 128) and the 64-element blocks above it (P a power of two >= 256); a leaf's running sums are a serial chain
+    // that walks from lane to lane; the carries come from replaying the recursion over the leaf totals (one lane).
+    PM2_DEV void cumsum_pairwise(const double (&w)[PPL], double (&c)[PPL])
+    {
+        constexpr int LPB = 64 / PPL;                // lanes per 64-element block
+        double sl[PPL];
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) sl[u] = 0.0;
+        const int blk = (tid * PPL) >> 6;            // 64-element block of the lane's particles
+        const int lib = tid % LPB;                   // lane inside the block
+        double *tot = lds<double>(L.leaf_tot), *car = lds<double>(L.leaf_carry);
+        double acc = 0.0;
+        for (int pass = 0; pass < 2; ++pass) {
+            // pass 0: every block but block 1 (whose chain continues block 0's: one leaf of 127 elements); pass 1: block 1
+            const bool mine = (pass == 0) ? (blk != 1) : (blk == 1);
+            double carry_in = 0.0;
+            if (pass == 1) carry_in = tot[0];
+            for (int t = 0; t < LPB; ++t) {
+                const double cin = shfl_d(acc, (lane + 63) & 63);
+                if (mine && lib == t) {
+                    double s = (t == 0) ? carry_in : cin;
+#pragma unroll
+                    for (int u = 0; u < PPL; ++u) {
+                        const int p = tid * PPL + u;
+                        if (p == 0) continue;                                      // c[1] = v1 is the recursion's seed
+                        const bool first = (p == 1) || ((p & 63) == 0 && p >= 128);
+                        s = first ? w[u] : s + w[u];
+                        sl[u] = s;
+                    }
+                    acc = s;
+                }
+            }
+            if (mine && lib == LPB - 1) tot[blk] = acc;
+            PM2_BARRIER();
+        }
+        if (tid == 0) {
+            // carries: replay the recursion over the leaf totals (program built at kernel start: op 0 = leaf, 3 = descend left,
+            // 1 = left done -> right child's carry, 2 = node done); leaf l's total sits at its LAST block
+            double cs[24], lt[24];
+            int sp = 0;
+            cs[0] = w[0];
+            double ret = 0.0;
+            const int nprog = sc()[SC_NPROG];
+            const u8 *prog = lds<u8>(L.leaf_prog);
+            const int *li1 = lds<int>(L.leaf_i1), *ln = lds<int>(L.leaf_n);
+            int leaf = 0;
+            for (int pc = 0; pc < nprog; ++pc) {
+                const int op = prog[pc];
+                if (op == 0) { car[leaf] = cs[sp]; ret = tot[(li1[leaf] + ln[leaf] - 1) >> 6]; ++leaf; }
+                else if (op == 3) { cs[sp + 1] = cs[sp]; ++sp; }
+                else if (op == 1) { lt[sp - 1] = ret; cs[sp] = cs[sp - 1] + ret; }
+                else { --sp; ret = lt[sp] + ret; }
+            }
+        }
+        PM2_BARRIER();
+#ifdef PM2_EMU
+        if (getenv("PM2_DEBUG") && tid == 0) {
+            fprintf(stderr, "E cumsum tot %.17g %.17g %.17g %.17g car %.17g %.17g %.17g nprog %d nleaf %d\n", tot[0], tot[1], tot[2], tot[3], car[0], car[1], car[2], sc()[SC_NPROG], sc()[SC_NLEAF]);
+        }
+#endif
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) {
+            const int p = tid * PPL + u;
+            const int leaf = (p < 128) ? 0 : (p >> 6) - 1;
+            c[u] = (p == 0) ? w[u] : car[leaf] + sl[u];
+        }
+    }
+
+    // ---- draw_partstar + gather + compact renumbering (src/misc.jl:27-47, src/pmdi.jl:318-340) ---------------------------------------
+    PM2_DEV void resample(long long pos, const double (&w)[PPL])
+    {
+        const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
+        const double usl = pmdi_arith::uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
+        double c[PPL];
+        cumsum_pairwise(w, c);
+        double *utab = lds<double>(L.tr);
+        u16 *jtab = lds<u16>(L.tr + L.rs_jtab), *raw = lds<u16>(L.tr + L.rs_raw), *anc = lds<u16>(L.tr + L.rs_anc);
+        double *red = lds<double>(L.red);
+        if (tid == T - 1) red[0] = c[PPL - 1];
+        // u += 1/particles by repeated addition (:34), exactly: h = 1/P is a power of two, so inside a binade every u + h is exact
+        // and only the additions that cross into the next binade round.  The lane replays the crossings up to its first slot
+        // and adds h for the following ones as the reference does.
+        {
+            const double h = 1.0 / (double)P;
+            const int j = tid * PPL;
+            double u = u01 / (double)P;
+            int done = 0;
+            while (done < j) {
+                int e;
+                (void)frexp(u, &e);                          // u in [2^(e-1), 2^e)
+                const double B = ldexp(1.0, e);
+                const double xx = (B - u) * (double)P;       // exact: B - u (same binade) and the power-of-two scale
+                double m = floor(xx);
+                if (m == xx) m -= 1.0;                       // largest m with u + m*h < B
+                if (m > (double)(j - done)) m = (double)(j - done);
+                if (m >= 1.0) { u = u + m * h; done += (int)m; }
+                if (done < j) { u = u + h; done += 1; }
+            }
+#pragma unroll
+            for (int uu = 0; uu < PPL; ++uu) { utab[j + uu] = u; u = u + h; }
+        }
+        PM2_BARRIER();
+        // slots taken up to and including particle p: J_p = #{ j : pprob[p] / last >= u_j } (:32-36)
+        {
+            const double last = red[0];
+#pragma unroll
+            for (int uu = 0; uu < PPL; ++uu) {
+                const double q = c[uu] / last;
+                int J = (int)((q - utab[0]) * (double)P) + 1;
+                if (J < 0) J = 0;
+                if (J > P) J = P;
+                while (J < P && q >= utab[J]) ++J;
+                while (J > 0 && !(q >= utab[J - 1])) --J;
+                jtab[tid * PPL + uu] = (u16)J;
+            }
+        }
+        PM2_BARRIER();
+        // slot j belongs to the first particle with J_p > j
+#pragma unroll
+        for (int uu = 0; uu < PPL; ++uu) {
+            const int j = tid * PPL + uu;
+            int lo = 0, hi = P - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)jtab[mid] > j) hi = mid; else lo = mid + 1; }
+            raw[j] = (u16)lo;
+        }
+        int js = (int)(usl * (double)P);                      // shuffle!, partstar[1] = 1, sort! (:43-45)
+        if (js >= P) js = P - 1;
+        PM2_BARRIER();
+#ifdef PM2_EMU
+        if (getenv("PM2_DEBUG") && tid == 0) {
+            fprintf(stderr, "E resample last %.17g u0 %.17g j %d raw:", red[0], utab[0], js);
+            for (int m = 0; m < P; ++m) fprintf(stderr, " %d", (int)raw[m]);
+            fprintf(stderr, "\n");
+        }
+#endif
+#pragma unroll
+        for (int uu = 0; uu < PPL; ++uu) {
+            const int p = tid * PPL + uu;
+            anc[p] = (p == 0) ? (u16)0 : (p <= js ? raw[p - 1] : raw[p]);
+            lw[uu] = 1.0;                                     // src/pmdi.jl:319
+        }
+        PM2_BARRIER();
+        // per dataset (:320-340); the u table is dead: its LDS holds the gather tables
+        u16 *scol = lds<u16>(L.tr), *mult = lds<u16>(L.tr + P * 2), *cmap = lds<u16>(L.tr + P * 4);
+        u8 *scsl = lds<u8>(L.tr + P * 6);
+        int *hist = lds<int>(L.tr + L.rs_hist);
+        for (int k = 0; k < K; ++k) {
+            const DV v = view(k);
+            int *dsc = v.dsc();
+            const int ncol_old = dsc[DS_NCOL], oldmax = dsc[DS_MAXID], ncls_old = dsc[DS_NCLS];
+#pragma unroll
+            for (int uu = 0; uu < PPL; ++uu) { const int p = tid * PPL + uu; scol[p] = (u16)col[k][uu]; scsl[p] = (u8)csl[k][uu]; }
+            for (int e = tid; e < ncol_old; e += T) mult[e] = 0;
+            for (int e = tid; e <= oldmax && e < v.idcap; e += T) hist[e] = 0;
+            if (tid < CLS) lds<int>(L.red)[16 + tid] = 0x7fffffff;
+            PM2_BARRIER();
+            // particle[:, partstar, k], particle_id[partstar, k] (:322-323): a particle takes its ancestor's column index and class
+#pragma unroll
+            for (int uu = 0; uu < PPL; ++uu) {
+                const int p = tid * PPL + uu;
+                const int an = anc[p];
+                col[k][uu] = scol[an]; csl[k][uu] = scsl[an];
+            }
+#pragma unroll
+            for (int uu = 0; uu < PPL; ++uu) {
+                // particles per old column, aggregated over the lanes that took the same one
+                const int cl = col[k][uu];
+                u64 rem = ~0ull;
+                while (rem) {
+                    const int l0 = pm2_ffs64(rem) - 1;
+                    const int c0 = readlane_i(cl, l0);
+                    const u64 m = PM2_BALLOT(cl == c0);
+                    if (lane == l0) {
+                        // (u16 table, 32-bit LDS atomics: two columns share a word)
+                        unsigned *wd = (unsigned *)mult + (c0 >> 1);
+                        pm2_atomic_add(wd, (unsigned)pm2_popc64(m) << ((c0 & 1) * 16));
+                    }
+                    rem &= ~m;
+                }
+                // lowest particle of every class
+                const int r = csl[k][uu];
+                for (int rr = 0; rr < ncls_old; ++rr) {
+                    const u64 m = PM2_BALLOT(r == rr);
+                    if (m && lane == pm2_ffs64(m) - 1) pm2_atomic_min(&lds<int>(L.red)[16 + rr], tid * PPL + uu);
+                }
+            }
+            PM2_BARRIER();
+            // new index of every column that kept a particle
+            int ncol_new = 0;
+            for (int b = 0; b < ncol_old; b += T) {
+                const int cc = b + tid;
+                const bool live = cc < ncol_old && mult[cc] != 0;
+                const u64 bal = PM2_BALLOT(live);
+                if (lane == 0) lds<int>(L.red)[32 + wave] = pm2_popc64(bal);
+                PM2_BARRIER();
+                int basew = ncol_new, tot = 0;
+                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[32 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
+                if (live) cmap[cc] = (u16)(basew + pm2_popc64(bal & ((1ull << lane) - 1ull)));
+                ncol_new += tot;
+                PM2_BARRIER();
+            }
+            // occupancy of every old id = sum over the live columns of (particles on the column) x (entries holding the id) (:338)
+            for (int idx = tid; idx < ncol_old * N; idx += T) {
+                const int cc = idx / N;
+                const int m = mult[cc];
+                if (m) {
+                    const int id = v.tab_get(cc, idx - cc * N);
+                    if (id < v.idcap) pm2_atomic_add(&hist[id], m); else pm2_atomic_add(PM2_G(int, v.ar.ncop()) + id, m);
+                }
+            }
+            PM2_BARRIER();
+            // sort(unique(particle)) ascending -> 1..U' (:329): ranks of the live ids; the map goes to the tgt table
+            int newmax = 0;
+            for (int b = 0; b < oldmax; b += T) {
+                const int id = 1 + b + tid;
+                int occ = 0;
+                if (id <= oldmax) occ = (id < v.idcap) ? hist[id] : PM2_G(int, v.ar.ncop())[id];
+                const bool live = occ != 0;
+                const u64 bal = PM2_BALLOT(live);
+                if (lane == 0) lds<int>(L.red)[32 + wave] = pm2_popc64(bal);
+                PM2_BARRIER();
+                int basew = newmax, tot = 0;
+                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[32 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
+                if (id <= oldmax) *v.tgt_p(id) = live ? basew + pm2_popc64(bal & ((1ull << lane) - 1ull)) + 1 : 0;
+                newmax += tot;
+                PM2_BARRIER();
+            }
+            // counts and cluster sizes move down with their ids, ascending (:336,:338): read a batch, barrier, write it
+            if (tid == 0) sc()[SC_TMP0] = 0;
+            for (int b = 0; b < oldmax; b += T) {
+                const int id = 1 + b + tid;
+                int nid = 0, occ = 0, cnv = 0;
+                if (id <= oldmax) {
+                    nid = *v.tgt_p(id);
+                    occ = (id < v.idcap) ? hist[id] : PM2_G(int, v.ar.ncop())[id];
+                    cnv = *v.cn_p(id);
+                    if (id >= v.idcap) PM2_G(int, v.ar.ncop())[id] = 0;
+                }
+                {
+                    const u64 mvb = PM2_BALLOT(nid != 0 && nid != id);
+                    if (lane == 0 && mvb) pm2_atomic_add(&sc()[SC_TMP0], pm2_popc64(mvb));
+                }
+                PM2_BARRIER();
+                if (id <= oldmax) {
+                    if (nid) { *v.counts_p(nid) = occ; *v.cn_p(nid) = cnv; }
+                    if (id > newmax) *v.counts_p(id) = 0;
+                }
+                PM2_BARRIER();
+            }
+            // ... and the statistics: clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending batches (:336)
+            {
+                const int D = ap->ds[k].D;
+                double *sb = PM2_G(double, v.ar.sb());
+                const long long nitems = (long long)oldmax * D;
+                for (long long b = 0; b < nitems; b += T) {
+                    const long long it = b + tid;
+                    const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
+                    const int nid = (it < nitems) ? *v.tgt_p(id) : 0;
+                    const bool mv = nid != 0 && nid != id;
+                    double sg = 0.0, bt = 0.0;
+                    if (mv) { sg = sb[((size_t)id * D + q) * 2]; bt = sb[((size_t)id * D + q) * 2 + 1]; }
+                    PM2_BARRIER();
+                    if (mv) { sb[((size_t)nid * D + q) * 2] = sg; sb[((size_t)nid * D + q) * 2 + 1] = bt; }
+                }
+            }
+            PM2_BARRIER();
+            // the cache follows the renumbering (same clusters under new ids)
+            if (wave == k) {
+                int *slot_id = lds<int>(v.base + L.slot_id);
+                int olds = 0, news = 0;
+                if (lane < NS) { olds = slot_id[lane]; news = olds ? *v.tgt_p(olds) : 0; }
+                PM2_WAVE_BARRIER();
+                if (lane < NS && olds) v.slot_set(olds, NONE8);
+                PM2_WAVE_BARRIER();
+                if (lane < NS) { slot_id[lane] = news; if (news) v.slot_set(news, lane); }
+            }
+            // the live columns, compacted and relabelled (:331-337), in rounds of whole columns (a round's targets lie at or below
+            // its sources, later rounds' sources above them)
+            {
+                const int cpr = (2 * T) / N;                       // columns per round: two entries per lane
+                for (int c0 = 0; c0 < ncol_old; c0 += cpr) {
+                    int nv[2], dc[2], dn[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int idx = h * T + tid;
+                        const int cc = c0 + idx / N, nn = idx - (idx / N) * N;
+                        nv[h] = 0; dc[h] = -1; dn[h] = nn;
+                        if (idx < cpr * N && cc < ncol_old && mult[cc] != 0) { nv[h] = *v.tgt_p(v.tab_get(cc, nn)); dc[h] = cmap[cc]; }
+                    }
+                    PM2_BARRIER();
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) if (dc[h] >= 0) v.tab_set(dc[h], dn[h], nv[h]);
+                    PM2_BARRIER();
+                }
+            }
+#pragma unroll
+            for (int uu = 0; uu < PPL; ++uu) col[k][uu] = cmap[col[k][uu]];
+            // classes that kept a particle, in leader order; leaders' columns
+            {
+                int *redi = lds<int>(L.red);
+                int newslot[CLS];
+                int nc2 = 0;
+#pragma unroll
+                for (int r = 0; r < CLS; ++r) {
+                    newslot[r] = -1;
+                    if (r < ncls_old && redi[16 + r] != 0x7fffffff) {
+                        int s = 0;
+                        for (int r2 = 0; r2 < ncls_old; ++r2) if (redi[16 + r2] < redi[16 + r]) ++s;
+                        newslot[r] = s;
+                        nc2 += 1;
+                    }
+                }
+                int cv[CLS];
+#pragma unroll
+                for (int r = 0; r < CLS; ++r) cv[r] = (r < ncls_old) ? lds<int>(v.base + L.clsval)[r] : 0;
+                PM2_BARRIER();
+#pragma unroll
+                for (int uu = 0; uu < PPL; ++uu) {
+                    const int p = tid * PPL + uu;
+                    const int r = csl[k][uu];
+                    int ns_ = 0;
+#pragma unroll
+                    for (int r2 = 0; r2 < CLS; ++r2) if (r2 == r) ns_ = newslot[r2];
+                    csl[k][uu] = ns_;
+                    if (redi[16 + r] == p) {
+                        lds<int>(v.base + L.clsval)[ns_] = cv[r]; lds<int>(v.base + L.clslead)[ns_] = p; lds<int>(v.base + L.leadcol)[ns_] = col[k][uu];
+                    }
+                }
+                if (tid == 0) {
+                    const int moved = sc()[SC_TMP0];
+                    dsc[DS_NCLS] = nc2; dsc[DS_NCOL] = ncol_new; dsc[DS_MAXID] = newmax;
+                    long long *w_ = wk(k);
+                    w_[WK_COLS] += ncol_old; w_[WK_MOVED] += moved; w_[WK_MOVE_EVENTS] += moved ? 1 : 0;
+                }
+            }
+            PM2_BARRIER();
+        }
+    }
+
+    // ---- the whole sweep -----------------------------------------------------------------------------------------------------------
+    PM2_DEV void run(const SweepArgs *ap_, int chain_)
+    {
+        ap = ap_; chain = chain_;
+        const SweepArgs &a = *ap;
+        tid = PM2_TID(); lane = tid & 63; wave = tid >> 6;
+        N = a.N; P = a.P; n = a.n; n1 = a.n1; iter = a.iter;
+        seed = a.seed + (unsigned long long)chain;
+        const long long t_start = PM2_CLOCK();
+        const bool owner = wave < K;
+        const int *order = PM2_G(const int, a.order) + (size_t)chain * n;
+        const double *logphi = PM2_G(const double, a.logphi) + (size_t)chain * a.npairs;
+        if (tid < SC_COUNT) sc()[tid] = 0;
+        if (tid < 8) stat()[tid] = 0;
+        if (tid < KMAX2 * 8) lds<long long>(L.wk)[tid] = 0;
+        PM2_BARRIER();
+        if (tid == 0) {
+            // leaf decomposition of Julia's accumulate_pairwise! over [1, P) and its recursion as a post-order program
+            int nl = 0, np = 0, sp = 0;
+            int st_i1[24], st_n[24], st_stage[24];
+            int *li1 = lds<int>(L.leaf_i1), *ln = lds<int>(L.leaf_n);
+            u8 *prog = lds<u8>(L.leaf_prog);
+            st_i1[0] = 1; st_n[0] = P - 1; st_stage[0] = 0;
+            while (sp >= 0) {
+                const int i1 = st_i1[sp], nn = st_n[sp];
+                if (nn < 128) { li1[nl] = i1; ln[nl] = nn; ++nl; prog[np++] = 0; --sp; }
+                else if (st_stage[sp] == 0) { st_stage[sp] = 1; prog[np++] = 3; ++sp; st_i1[sp] = i1; st_n[sp] = nn >> 1; st_stage[sp] = 0; }
+                else if (st_stage[sp] == 1) { st_stage[sp] = 2; prog[np++] = 1; const int n2 = nn >> 1; ++sp; st_i1[sp] = i1 + n2; st_n[sp] = nn - n2; st_stage[sp] = 0; }
+                else { prog[np++] = 2; --sp; }
+            }
+            sc()[SC_NLEAF] = nl; sc()[SC_NPROG] = np;
+        }
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) lw[u] = a.lw_init;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) { col[k][u] = 0; csl[k][u] = 0; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { c_mu[s] = 0.0; c_lam[s] = 1.0; c_sg[s] = 0.0; c_bt[s] = 0.5; }
+        PM2_BARRIER();
+        if (owner) prefix(wave);
+        PM2_BARRIER();
+
+        // the observation row of the owner wave's dataset, one step ahead (lane = feature)
+        double xnext = 0.0;
+        int i_next = order[n1 - 1];
+        if (owner && lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+        int failed = 0;
+        for (long long pos = n1 - 1; pos < n; ++pos) {
+            const int i = i_next;
+            const double x = xnext;
+            if (pos + 1 < n) {
+                i_next = order[pos + 1];
+                if (owner && lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+            }
+            // ---- cluster phase: the K datasets side by side, one owner wave each
+            if (owner) phase_a(wave, x, i, pos);
+            PM2_BARRIER();
+            if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
+            // ---- particle phase (all lanes, all datasets): allocation draw (:251-265), census, weights (:227,:245), Phi (:312-314)
+            int ns_[K][PPL], cc_[K][PPL];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const DV v = view(k);
+                const int ns0 = v.dsc()[DS_NS0];
+                unsigned packed = 0;
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) {
+                    const int p = tid * PPL + u;
+                    const int r = csl[k][u];
+                    const double *row = v.cdf_row(r);
+                    const int hot = (int)row[N + 1];
+                    int ns = 0;
+                    if (p == 0) ns = ns0;                                       // reference trajectory (:262)
+                    else if (hot >= 0) ns = hot;                                // one-hot CDF: no random number needed
+                    else {
+                        const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                        // first label whose CDF exceeds u (:252-260) = the number of leading entries that do not exceed it
+                        for (int t = 0; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
+                    }
+                    lw[u] = lw[u] + row[N];                                     // logweight[p] += increment (:227,:245), dataset order
+                    const int c = v.tab_get(col[k][u], ns);                     // sstar_id (:264)
+                    ns_[k][u] = ns; cc_[k][u] = c;
+                    packed |= (unsigned)ns << (8 * (u & 3));
+                    if ((u & 3) == 3 || u == PPL - 1) {                         // sstar[p, i, k] (:265), four particles per store
+                        u8 *ss = v.ar.sstar() + (size_t)pos * P + (size_t)tid * PPL + (u & ~3);
+                        if (PPL >= 4) *PM2_G(unsigned, ss) = packed;
+                        else if (PPL == 2) *PM2_G(u16, ss) = (u16)packed;
+                        else *PM2_G(u8, ss) = (u8)packed;
+                        packed = 0;
+                    }
+                    census(v, r, col[k][u], ns, c, p);
+                }
+            }
+            if (K > 1) {                                                        // Phi_upweight! (src/misc.jl:50-59)
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) {
+                    int pr = 0;
+                    double wv_ = lw[u];
+#pragma unroll
+                    for (int k1 = 0; k1 < K - 1; ++k1)
+#pragma unroll
+                        for (int k2 = k1 + 1; k2 < K; ++k2) { wv_ += (ns_[k1][u] == ns_[k2][u]) ? logphi[pr] : 0.0; ++pr; }
+                    lw[u] = wv_;
+                }
+            }
+            double *red = lds<double>(L.red);
+            {
+                double mx = lw[0];
+#pragma unroll
+                for (int u = 1; u < PPL; ++u) mx = (lw[u] > mx) ? lw[u] : mx;
+                mx = wave_max_d(mx);
+                if (lane == 0) red[wave] = mx;
+            }
+            PM2_BARRIER();
+            // ---- calc_ESS (src/misc.jl:15-25), first half; the bookkeeping phase of the owner waves
+            double w[PPL];
+            double mx = red[0];
+            for (int w_ = 1; w_ < T / 64; ++w_) mx = (red[w_] > mx) ? red[w_] : mx;
+            {
+                double sa = 0.0, sq = 0.0;
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) { w[u] = exp(lw[u] - mx); sa += w[u]; sq += w[u] * w[u]; }
+                sa = wave_sum_d(sa); sq = wave_sum_d(sq);
+                if (lane == 0) { red[8 + wave] = sa; red[12 + wave] = sq; }
+            }
+            if (owner) phase_c(wave, x, pos);
+            PM2_BARRIER();
+            if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
+            // ---- every particle follows its group: new column, new class slot
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const DV v = view(k);
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) {
+                    const int cl = col[k][u], ns = ns_[k][u];
+                    const u64 wm = *v.wmask_p(cl);
+                    if ((wm >> ns) & 1ull) {
+                        const int bi = *v.cbi_p(cl);
+                        const int inpl = (bi & 0xff) - 1, base = bi >> 8;
+                        const int rnk = pm2_popc64(wm & ((1ull << ns) - 1ull));
+                        col[k][u] = (inpl >= 0) ? (ns == inpl ? cl : base + rnk - 1) : base + rnk;
+                    }
+                    csl[k][u] = lds<u8>(v.base + L.knew)[csl[k][u] * N + ns];
+                }
+            }
+            double sa = 0.0, sq = 0.0;
+            for (int w_ = 0; w_ < T / 64; ++w_) { sa += red[8 + w_]; sq += red[12 + w_]; }
+            double ess = (sa * sa) / sq;
+            // The tree-ordered sums agree with calc_ESS's sequential loop to ~1e-13 relative; the decision is a comparison, so when
+            // ESS lands that close to P/2 (k equal weights and the rest negligible give exactly k in the reference's order, and
+            // k = P/2 does happen) the sums are redone in the reference's order by one lane.
+            if (fabs(ess - 0.5 * (double)P) <= 1e-9 * (double)P) {
+                double *wt = lds<double>(L.tr);
+                PM2_BARRIER();
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) wt[tid * PPL + u] = w[u];
+                PM2_BARRIER();
+                if (tid == 0) {
+                    double na = 0.0, nb = 0.0;
+                    for (int p = 0; p < P; ++p) { na += wt[p]; nb += wt[p] * wt[p]; }
+                    red[40] = (na * na) / nb;
+                }
+                PM2_BARRIER();
+                ess = red[40];
+                PM2_BARRIER();
+            }
+            const bool res = ess <= 0.5 * (double)P;              // src/pmdi.jl:317
+            if (res) {
+                if (tid == 0) stat()[1] += 1;
+                resample(pos, w);
+            }
+            if (a.trace_on && tid == 0) {
+                double *tr = PM2_G(double, a.trace) + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
+                tr[0] = ess; tr[1] = res ? 1.0 : 0.0;
+                for (int k = 0; k < K; ++k) { tr[2 + k] = (double)view(k).dsc()[DS_MAXID]; tr[2 + K + k] = (double)view(k).dsc()[DS_NCLS]; }
+            }
+        }
+        if (failed) {
+            if (tid == 0) {
+                PM2_G(int, a.err)[chain] = (failed == 1) ? -4 : PMDI_S2_REQUEUE;          // PMDI_E_POOL / sweep again with the general kernel
+                PM2_G(long long, a.stats)[(size_t)chain * 8 + 7] = failed;                // (why: 2 reachable clusters, 3 chosen clusters, 4 classes)
+                PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
+            }
+            if (failed == 1) {
+                const int *s_in = PM2_G(const int, a.s_in) + (size_t)chain * K * n;
+                int *s_out = PM2_G(int, a.s_out) + (size_t)chain * K * n;
+                for (long long e = tid; e < (long long)K * n; e += T) s_out[e] = s_in[e];
+            }
+            return;
+        }
+        finish(t_start);
+    }
+
+    // ---- particle pick (src/pmdi.jl:345-350), s = sstar[p_star, :, :] (:373), counters, the state the debug export reads --------------
+    PM2_DEV void finish(long long t_start)
+    {
+        const SweepArgs &a = *ap;
+        double *red = lds<double>(L.red);
+        double *wt = lds<double>(L.tr);
+        const int *order = PM2_G(const int, a.order) + (size_t)chain * n;
+        PM2_BARRIER();
+        {
+            double mx = lw[0];
+#pragma unroll
+            for (int u = 1; u < PPL; ++u) mx = (lw[u] > mx) ? lw[u] : mx;
+            mx = wave_max_d(mx);
+            if (lane == 0) red[wave] = mx;
+        }
+        PM2_BARRIER();
+        double mx = red[0];
+        for (int w_ = 1; w_ < T / 64; ++w_) mx = (red[w_] > mx) ? red[w_] : mx;
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) wt[tid * PPL + u] = exp(lw[u] - mx);
+        PM2_BARRIER();
+        if (tid == 0) {   // StatsBase.sample(::Weights): sequential sum and scan, as the oracle
+            double sum = 0.0;
+            for (int p = 0; p < P; ++p) sum += wt[p];
+            const double t = pmdi_arith::uniform01(seed, iter, 0, 0, 0, SITE_PSTAR) * sum;
+            int ip = 0;
+            double cw = wt[0];
+            while (cw < t && ip < P - 1) { ++ip; cw += wt[ip]; }
+            sc()[SC_PSTAR] = ip;
+        }
+        PM2_BARRIER();
+        const int pstar = sc()[SC_PSTAR];
+        for (long long pp = tid; pp < n; pp += T) {
+            const int i = order[pp];
+            for (int k = 0; k < K; ++k) {
+                int val;
+                if (pp < n1 - 1) val = PM2_G(const int, a.s_in)[((size_t)chain * K + k) * n + i];          // sstar[:, i, k] .= s[i, k] (:204)
+                else val = PM2_G(const u8, view(k).ar.sstar())[(size_t)pp * P + pstar];
+                PM2_G(int, a.s_out)[((size_t)chain * K + k) * n + i] = val;
+            }
+        }
+        if (a.lw_out)
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) PM2_G(double, a.lw_out)[(size_t)chain * P + tid * PPL + u] = lw[u];
+        // what pmdi_export_state reads: the columns, the column and class of every particle, counts, cluster sizes
+        for (int k = 0; k < K; ++k) {
+            const DV v = view(k);
+            const int ncol = v.dsc()[DS_NCOL], maxid = v.dsc()[DS_MAXID];
+            int *tg = PM2_G(int, v.ar.tabg());
+            for (int e = tid; e < ncol * N && e < v.cols_l * N; e += T) tg[e] = (int)lds<u16>(v.base + L.tab)[e];
+            int *cg = PM2_G(int, v.ar.colg()), *pg = PM2_G(int, v.ar.pidg());
+#pragma unroll
+            for (int u = 0; u < PPL; ++u) { cg[tid * PPL + u] = col[k][u]; pg[tid * PPL + u] = lds<int>(v.base + L.clsval)[csl[k][u]]; }
+            int *cng = PM2_G(int, v.ar.cn()), *ctg = PM2_G(int, v.ar.counts());
+            for (int id = tid; id < v.idcap && id <= a.cap; id += T) { cng[id] = (id <= maxid) ? lds<int>(v.base + L.cn)[id] : cng[id]; ctg[id] = (id <= maxid) ? lds<int>(v.base + L.counts)[id] : 0; }
+            for (int id = maxid + 1 + tid; id <= a.cap; id += T) ctg[id] = 0;
+            if (tid == 0) {
+                PM2_G(int, a.kstate)[((size_t)chain * PMDI_KMAX_I + k) * 2] = maxid;
+                PM2_G(int, a.kstate)[((size_t)chain * PMDI_KMAX_I + k) * 2 + 1] = 0;
+            }
+        }
+        if (tid == 0) {
+            long long *st = PM2_G(long long, a.stats) + (size_t)chain * 8;
+            const long long *s = stat();
+            PM2_G(int, a.pstar)[chain] = pstar;
+            st[ST_NOPS] = s[0]; st[ST_NRESAMPLE] = s[1]; st[ST_NCLONES] = s[2]; st[ST_MAXID] = s[3]; st[ST_SUMCLASSES] = s[4];
+            st[5] = s[5]; st[6] = 0; st[7] = 0;
+            if (!a.err_keep) PM2_G(int, a.err)[chain] = 0;
+            PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
+        }
+        if (a.work && tid < K * 8) PM2_G(long long, a.work)[((size_t)chain * PMDI_KMAX_I) * 8 + tid] = lds<long long>(L.wk)[tid];
+    }
+#undef L
+};
+
+}  // namespace pmdi_s2

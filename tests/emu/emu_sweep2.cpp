@@ -1,0 +1,162 @@
+// emu_sweep2.cpp -- TEST INFRASTRUCTURE ONLY.  Runs the device code of the settled-chain kernel
+// (particlemdi.jl_amd/csrc/pmdi_sweep2_body.h) on the host, one emulated workgroup (tests/emu/wavesim.h), so that its logic can be
+// checked against the oracle without a GPU.  Not linked into, loaded by or shipped with the product library.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define PM2_EMU 1
+#include "../../particlemdi.jl_amd/csrc/pmdi_sweep2_body.h"
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// the arena of pmdi_api.cpp's layout_arena (sweep state), restated for host memory
+size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_sstar)
+{
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t ids = (size_t)cap + 1;
+    d.o_particle[0] = take((size_t)N * P * 4);
+    d.o_particle[1] = take((size_t)N * P * 4);
+    d.o_col = take((size_t)P * 4);
+    d.o_cgrp = take((size_t)N * P * 8);
+    d.o_pid = take((size_t)P * 4);
+    d.o_sid = take((size_t)P * 4);
+    d.o_kv = take((size_t)P * 4);
+    d.o_newid = take((size_t)N * P * 4);
+    d.o_counts = take(ids * 4);
+    d.o_ncop = take(ids * 4);
+    d.o_firstc = take(ids * 4);
+    d.o_lp = take(ids * 8);
+    d.o_sstar = take((size_t)n_rows_sstar * P);
+    d.o_clslead = take((size_t)P * 4);
+    d.o_clsval = take((size_t)P * 4);
+    d.o_cdf = take((size_t)P * (N + 2) * 8);
+    d.o_dl = take((size_t)3 * P * 4);
+    d.o_cn = take(ids * 4);
+    d.o_sb = take(ids * d.D * 16);
+    return o;
+}
+
+struct Emu {
+    int K, N, P;
+    long long n, cap;
+    unsigned long long seed;
+    int q1;
+    std::vector<std::vector<double>> x, gtab;
+    std::vector<std::vector<char>> arena;
+    DsetDev ds[PMDI_KMAX_I];
+    int Dmax = 0, sumD = 0;
+    int cols_l, idcap;
+};
+
+struct RunArg { const SweepArgs *a; int K, PPL; };
+
+template <int K, int PPL> void body(const SweepArgs *a)
+{
+    pmdi_s2::Sweep2<K, PPL> s;
+    s.run(a, 0);
+}
+
+void entry(void *p)
+{
+    const RunArg *r = (const RunArg *)p;
+#define CASE(K_, P_) if (r->K == K_ && r->PPL == P_) return body<K_, P_>(r->a)
+    CASE(1, 1); CASE(1, 2); CASE(1, 4); CASE(2, 1); CASE(2, 2); CASE(2, 4); CASE(3, 1); CASE(3, 2); CASE(3, 4); CASE(4, 1); CASE(4, 2); CASE(4, 4);
+#undef CASE
+    fprintf(stderr, "emu: unsupported K=%d PPL=%d\n", r->K, r->PPL);
+    abort();
+}
+
+}  // namespace
+
+extern "C" {
+
+// data[k]: n x D_k row-major doubles
+void *emu_create(int K, long long n, int N, int P, const int *D, const double *const *data, unsigned long long seed, int q1,
+                 int cols_l, int idcap)
+{
+    if (K < 1 || K > pmdi_s2::KMAX2 || P % 256 != 0 || (P / 256 != 1 && P / 256 != 2 && P / 256 != 4) || N > 64) return nullptr;
+    Emu *e = new Emu();
+    e->K = K; e->N = N; e->P = P; e->n = n; e->cap = (long long)N * P + 1; e->seed = seed; e->q1 = q1;
+    e->cols_l = cols_l; e->idcap = idcap;
+    memset(e->ds, 0, sizeof(e->ds));
+    e->x.resize(K); e->gtab.resize(K); e->arena.resize(K);
+    int flag_off = 0;
+    for (int k = 0; k < K; ++k) {
+        if (D[k] > 64) { delete e; return nullptr; }
+        DsetDev &d = e->ds[k];
+        d.kind = K_GAUSSIAN; d.D = D[k]; d.L = 0; d.flag_off = flag_off;
+        flag_off += D[k];
+        if (D[k] > e->Dmax) e->Dmax = D[k];
+        e->x[k].assign(data[k], data[k] + (size_t)n * D[k]);
+        d.xf = e->x[k].data();
+        e->gtab[k].resize((size_t)n + 1);
+        for (long long m = 0; m <= n; ++m) {
+            const double nn = (double)m;
+            e->gtab[k][m] = (log(1.0 / sqrt(M_PI)) + lgamma(0.5 * nn + 1.0)) - lgamma(0.5 * nn + 0.5);   // as pmdi_create
+        }
+        d.gtab = e->gtab[k].data();
+        d.stride = layout_arena(d, N, P, e->cap, n);
+        e->arena[k].assign(d.stride, 0);
+        d.arena = e->arena[k].data();
+    }
+    e->sumD = flag_off;
+    return e;
+}
+
+void emu_destroy(void *h) { delete (Emu *)h; }
+
+long long emu_lds_bytes(void *h)
+{
+    Emu *e = (Emu *)h;
+    S2Layout L;
+    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, L);
+    return L.total;
+}
+
+// one sweep of one chain; 0-based labels / order; returns err (0 ok, 1 requeue, -4 pool)
+int emu_sweep(void *h, long long iter, const int *s_in, const int *order, long long n1, const double *Pi, const double *logphi,
+              const unsigned char *flags, double lw_init, int *s_out, double *lw_out, int *pstar, long long *stats, long long *work,
+              double *trace, int *particle, int *counts, int *cn, int *maxid_out)
+{
+    Emu *e = (Emu *)h;
+    SweepArgs a;
+    memset(&a, 0, sizeof(a));
+    a.K = e->K; a.N = e->N; a.P = e->P; a.cap = (int)e->cap;
+    a.Dmax = e->Dmax; a.sumD = e->sumD; a.npairs = e->K > 1 ? e->K * (e->K - 1) / 2 : 1;
+    a.q1 = e->q1; a.q2 = 0; a.trace_on = trace ? 1 : 0;
+    a.iter = (unsigned)iter; a.n = e->n; a.n1 = n1; a.seed = e->seed; a.lw_init = lw_init;
+    for (int k = 0; k < e->K; ++k) a.ds[k] = e->ds[k];
+    a.s_in = s_in; a.order = order; a.Pi = Pi; a.logphi = logphi; a.flags = flags;
+    a.s_out = s_out; a.lw_out = lw_out; a.pstar = pstar; a.stats = stats; a.trace = trace;
+    int err = 0;
+    long long cost = 0;
+    std::vector<int> kstate(PMDI_KMAX_I * 2, 0);
+    std::vector<long long> wk(PMDI_KMAX_I * 8, 0);
+    a.err = &err; a.cost = &cost; a.kstate = kstate.data(); a.work = wk.data();
+    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, a.s2);
+    RunArg r{&a, e->K, e->P / 256};
+    wavesim::run_block(256, 0, (size_t)a.s2.total, entry, &r);
+    if (work) for (int k = 0; k < e->K; ++k) for (int j = 0; j < 8; ++j) work[k * 8 + j] = wk[k * 8 + j];
+    if (err == 0 && particle) {
+        // what pmdi_export_state does: expand the columns back to particle[n, p, k]
+        for (int k = 0; k < e->K; ++k) {
+            const DsetDev &d = e->ds[k];
+            const int *tab = (const int *)(d.arena + d.o_particle[0]);
+            const int *col = (const int *)(d.arena + d.o_col);
+            for (int p = 0; p < e->P; ++p)
+                for (int nn = 0; nn < e->N; ++nn) particle[((size_t)k * e->P + p) * e->N + nn] = tab[(size_t)col[p] * e->N + nn];
+            const int *cc = (const int *)(d.arena + d.o_counts), *cnn = (const int *)(d.arena + d.o_cn);
+            for (long long id = 1; id <= e->cap; ++id) { counts[(size_t)k * e->cap + (id - 1)] = cc[id]; cn[(size_t)k * e->cap + (id - 1)] = cnn[id]; }
+            maxid_out[k] = kstate[k * 2];
+        }
+    }
+    return err;
+}
+
+}  // extern "C"

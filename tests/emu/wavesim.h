@@ -133,7 +133,16 @@ inline void run_block(int T, int bid, size_t lds_bytes, void (*entry)(void *), v
     const int nw = (T + 63) / 64;
     for (;;) {
         bool progressed = false, all_done = true;
-        for (int w = 0; w < nw; ++w) {
+        int worder[16];
+        for (int w = 0; w < nw; ++w) worder[w] = w;
+        if (blk.rng)                                 // ... and the waves of the workgroup in a random order, too
+            for (int i = nw - 1; i > 0; --i) {
+                blk.rng = blk.rng * 1664525u + 1013904223u;
+                const int j = (int)((blk.rng >> 8) % (unsigned)(i + 1));
+                const int t = worder[i]; worder[i] = worder[j]; worder[j] = t;
+            }
+        for (int wi = 0; wi < nw; ++wi) {
+            const int w = worder[wi];
             const int lo = w * 64, hi = (lo + 64 < T) ? lo + 64 : T;
             // run every runnable lane of the wave up to its next collective
             int order[64];
