@@ -12,8 +12,9 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.environ.get("PMDI_LIB_PATH") or os.path.join(_PKG, "libpmdi_hip.so")   # override: A/B builds only
-_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_kernels.hip", "pmdi_hypers.hip", "pmdi_api.cpp", "pmdi_csv.cpp", "pmdi_comm.cpp")]
+_SOURCES = [os.path.join(_PKG, "csrc", f) for f in ("pmdi_sweep.hip", "pmdi_sweep2.hip", "pmdi_kernels.hip", "pmdi_hypers.hip", "pmdi_api.cpp", "pmdi_csv.cpp", "pmdi_comm.cpp")]
 _HEADERS = [os.path.join(_PKG, "csrc", "pmdi_internal.h"), os.path.join(_PKG, "csrc", "pmdi_device.h"),
+            os.path.join(_PKG, "csrc", "pmdi_sweep2_body.h"), os.path.join(_PKG, "csrc", "pmdi_arith.h"),
             os.path.join(_ROOT, "include", "pmdi_hip.h")]
 
 GAUSSIAN, CATEGORICAL, NEGBINOM = 0, 1, 2
@@ -34,7 +35,7 @@ EXPORTS = [
     "pmdi_csv_open", "pmdi_csv_write_row", "pmdi_csv_write_gibbs", "pmdi_csv_open_features", "pmdi_csv_write_flags",
     "pmdi_csv_close", "pmdi_csv_read_allocations", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz", "pmdi_is_split",
     "pmdi_comm_unique_id", "pmdi_comm_init_rank", "pmdi_comm_init_all", "pmdi_comm_destroy", "pmdi_comm_rank", "pmdi_comm_size",
-    "pmdi_allgather_samples",
+    "pmdi_allgather_samples", "pmdi_settled_kernel",
 ]
 
 
@@ -181,6 +182,8 @@ def lib():
     L.pmdi_allgather_samples.restype = C.c_int
     L.pmdi_allgather_samples.argtypes = [vp, i32, vp, vp, i64, vp]
     L.pmdi_is_split.argtypes = [vp]
+    L.pmdi_settled_kernel.restype = C.c_int
+    L.pmdi_settled_kernel.argtypes = [vp, vp]
     L.pmdi_shader_clock_hz.restype = i64
     L.pmdi_shader_clock_hz.argtypes = [vp]
     L.pmdi_work_counters.restype = C.c_int
@@ -276,6 +279,7 @@ class Sweeper:
         self.lds_bytes = L.pmdi_lds_bytes(h)
         self.clock_hz = L.pmdi_shader_clock_hz(h)
         self.split = bool(L.pmdi_is_split(h))
+        self.settled = bool(L.pmdi_settled_kernel(h, None))
         self.npairs = max(1, self.K * (self.K - 1) // 2)
         self._keep = None  # the library copied the data
 
@@ -350,6 +354,13 @@ class Sweeper:
         _check(lib().pmdi_label_counts_device(self.h, C.c_void_p(ds.data_ptr()), C.c_void_p(out.data_ptr()),
                                               C.c_void_p(st.cuda_stream)))
         return out.cpu().numpy().astype(np.int64)
+
+    def given_back(self):
+        """Chains the settled-chain kernel has handed back to the general kernel so far: (reachable clusters, chosen clusters,
+        particle classes, total)."""
+        out = np.zeros(4, dtype=np.int64)
+        lib().pmdi_settled_kernel(self.h, _ptr(out))
+        return out
 
     def chain_costs(self):
         out = np.zeros(self.C, dtype=np.int64)

@@ -145,7 +145,7 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_args4, d_args5, d_requeue, d_requeue_total, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
     int ksplit = 0;
     int ksplit_batch = 0;        // split mode: chain slots per launch when n_chains * K workgroups are not resident at once (0 = one launch)
     bool have_order = false;
@@ -155,6 +155,9 @@ struct pmdi_handle {
     hipEvent_t ring_ev[RING] = {};
     bool ring_used[RING] = {};
     int ring_head = 0;
+    // settled-chain kernel (pmdi_sweep2.hip): takes the light group of a sweep when the configuration is one it is built for
+    bool s2_ok = false;
+    S2Layout s2{};
     int err_keep = 0;            // set by the device-resident driver around its sweeps (pmdi_gibbs_step)
     int children = 0;            // live pmdi_gibbs / cluster-batch objects: pmdi_destroy refuses while > 0
     // feature selection
@@ -226,6 +229,9 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.anclog = (int *)h->d_anclog.p; a.evpos = (int *)h->d_evpos.p;
     a.ksplit = h->ksplit; a.xcnt = (int *)h->d_xcnt.p; a.xinc = (double *)h->d_xinc.p; a.xlab = (int *)h->d_xlab.p; a.xhdr = (unsigned long long *)h->d_xhdr.p;
     a.chain_order = h->have_order ? (const int *)h->d_lorder.p : nullptr;
+    a.s2 = h->s2;
+    a.requeue = h->s2_ok ? (int *)h->d_requeue.p : nullptr;
+    a.requeue_total = h->s2_ok ? (long long *)h->d_requeue_total.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
     for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
@@ -317,8 +323,22 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
         al.group_sel = 0; al.rank_lo = 0; al.rank_hi = C;
         al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds; al.col_lds = h->l_col_lds;
         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
-        e = launch_maybe_batched(h, al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
-        if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (light group): %s", hipGetErrorString(e));
+        if (h->s2_ok) {
+            // the light chains go to the settled-chain kernel; the ones it gives back (a step that does not fit its tables) are
+            // swept again, from the start, by the general kernel right behind it on the same stream
+            int idx;
+            SweepArgs *slot = next_slot(h, h->stream2, &idx);
+            e = pmdi_launch_sweep2(al, (SweepArgs *)h->d_args4.p, C, h->stream2, slot);
+            if (e == hipSuccess && idx >= 0) { e = hipEventRecord(h->ring_ev[idx], h->stream2); h->ring_used[idx] = true; }
+            if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (settled chains): %s", hipGetErrorString(e));
+            SweepArgs ar = al;
+            ar.group_flag = nullptr; ar.requeue_only = 1;
+            e = launch_one(h, ar, (SweepArgs *)h->d_args5.p, C, 256, h->stream2);
+            if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (chains given back by the settled-chain kernel): %s", hipGetErrorString(e));
+        } else {
+            e = launch_maybe_batched(h, al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
+            if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (light group): %s", hipGetErrorString(e));
+        }
         HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
         HIP_TRY(hipStreamWaitEvent(st, h->ev_join, 0));
         // re-arm the start gate only here: `st` has now joined BOTH gated consumers (its own wait and stream2's), so neither can
@@ -354,7 +374,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->ring) (void)hipHostFree(h->ring);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_args4, &h->d_args5, &h->d_requeue, &h->d_requeue_total, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -567,8 +587,30 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 }
             }
         }
+        // the settled-chain kernel: all-Gaussian configurations of the shapes it is built for, the reference's default quirk modes,
+        // one workgroup per chain; its LDS tables sized so that two chains share a CU (fewer LDS columns / ids if need be)
+        {
+            bool ok = env_int("PMDI_SETTLED", 1) != 0 && cfg->block_threads == 0 && !h->ksplit && cfg->q1_mode == 0 && cfg->q2_mode == 0 &&
+                      pmdi_sweep2_supports(K, N, P, h->Dmax, cap);
+            for (int k = 0; k < K && ok; ++k) ok = h->ds[k].kind == K_GAUSSIAN;
+            if (ok) {
+                int cols_l = env_int("PMDI_S2_COLS", 64), idcap = env_int("PMDI_S2_IDCAP", 128);
+                if (cols_l < 1) cols_l = 1;
+                if (cols_l > P) cols_l = P;
+                if (idcap < 8) idcap = 8;
+                if (idcap > 4096) idcap = 4096;
+                pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
+                while (h->s2.total > 80 * 1024 && (cols_l > 16 || idcap > 64)) {
+                    if (cols_l > 16) cols_l /= 2; else idcap /= 2;
+                    pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
+                }
+                ok = h->s2.total <= 80 * 1024;
+            }
+            h->s2_ok = ok;
+        }
         // automatic width: split the chains of a sweep into a heavy and a light launch
-        h->split = cfg->block_threads == 0 && h->T > 256 && env_int("PMDI_SPLIT", 1) != 0;
+        h->split = cfg->block_threads == 0 && (h->T > 256 || h->s2_ok) && env_int("PMDI_SPLIT", 1) != 0;
+        if (!h->split) h->s2_ok = false;
         h->light_ids = env_int("PMDI_LIGHT_IDS", 40);
         if (h->split) {
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
@@ -606,8 +648,12 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
         (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
         (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
-        (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)))
+        (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)) ||
+        (rc = h->d_args4.ensure(sizeof(SweepArgs))) || (rc = h->d_args5.ensure(sizeof(SweepArgs))) || (rc = h->d_requeue.ensure((size_t)C * 4)) ||
+        (rc = h->d_requeue_total.ensure(4 * 8)))
         return bail(rc);
+    if (hipMemset(h->d_requeue.p, 0, (size_t)C * 4) != hipSuccess || hipMemset(h->d_requeue_total.p, 0, 32) != hipSuccess)
+        return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));
     {   // pinned staging ring of the argument blocks (asynchronous launches); without it the copies fall back to pageable memory
         void *ring = nullptr;
         if (hipHostMalloc(&ring, sizeof(SweepArgs) * pmdi_handle::RING, hipHostMallocDefault) == hipSuccess) {
@@ -626,7 +672,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if (cfg->q2_mode == 1 &&       // ancestor log of the resampling events: up to one per swept observation
         ((rc = h->d_anclog.ensure((size_t)C * (size_t)n * P * 4)) || (rc = h->d_evpos.ensure((size_t)C * 2 * (size_t)n * 4))))
         return bail(rc);
-    if (hipMemset(h->d_group.p, 1, (size_t)C) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));   // first sweep: every chain is heavy
+    // first sweep: every chain is heavy (PMDI_SETTLED=2: every chain starts on the settled-chain kernel -- tests of its hand-back path)
+    if (hipMemset(h->d_group.p, (h->s2_ok && getenv("PMDI_SETTLED") && atoi(getenv("PMDI_SETTLED")) == 2) ? 0 : 1, (size_t)C) != hipSuccess)
+        return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));
 
     // null-cluster marginal (src/pmdi.jl:120-128): all rows in one cluster, all features on
     {
@@ -704,6 +752,19 @@ int64_t pmdi_lds_bytes(const pmdi_handle *h)
     return (int64_t)pmdi_sweep_lds_bytes(a, h->T);
 }
 int pmdi_sum_D(const pmdi_handle *h) { return h ? h->sumD : 0; }
+int pmdi_settled_kernel(pmdi_handle *h, int64_t *given_back4)
+{
+    if (!h) return 0;
+    if (given_back4) {
+        given_back4[0] = given_back4[1] = given_back4[2] = given_back4[3] = 0;
+        if (h->s2_ok) {
+            if (hipSetDevice(h->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(given_back4, h->d_requeue_total.p, 32, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(PMDI_E_DEVICE, "pmdi_settled_kernel: reading the counters failed");
+        }
+    }
+    return h->s2_ok ? 1 : 0;
+}
 int64_t pmdi_pool_cap(const pmdi_handle *h) { return h ? h->cap : 0; }
 int pmdi_categorical_L(const pmdi_handle *h, int32_t k) { return (h && k >= 0 && k < h->cfg.K) ? h->ds[k].L : 0; }
 

@@ -4,7 +4,7 @@
 // infrastructure).  Compile with -ffp-contract=off.  Reference lines are file:line relative to /root/reference.
 #pragma once
 #if defined(__HIPCC__)
-#define PMDI_HD __host__ __device__ __forceinline__
+#define PMDI_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define PMDI_HD inline
 #endif

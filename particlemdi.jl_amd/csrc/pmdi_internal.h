@@ -131,7 +131,9 @@ struct SweepArgs {
     int group_sel;              // this launch sweeps the chains whose flag equals group_sel (when group_flag != null)
     int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
     S2Layout s2;                // settled-chain kernel: its LDS layout (cols_l / idcap = columns / cluster ids kept in LDS)
-    int requeue_only;           // 1: this launch of the general kernel sweeps the chains the settled-chain kernel gave back (err == 1)
+    int *requeue;               // [chain] 1: the settled-chain kernel gave the chain back (it does not fit its tables): sweep it again
+    long long *requeue_total;   // [4] chains given back so far, by reason (reachable clusters, chosen clusters, classes), and in total
+    int requeue_only;           // 1: this launch of the general kernel sweeps exactly those chains
     int slot_base;              // split mode launched in residency-sized batches: first chain slot of this launch
     int err_keep;               // 1: a successful sweep leaves err[chain] as it is (device-resident chains: the first error sticks)
 };
@@ -194,6 +196,11 @@ size_t pmdi_sweep_lds_bytes(const SweepArgs &a, int T);
 hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains, int T, hipStream_t stream, SweepArgs *staging = nullptr);
 // workgroups of the sweep kernel build (T threads, the argument block's LDS layout) that one CU holds at once
 hipError_t pmdi_sweep_blocks_per_cu(const SweepArgs &a, int T, int *blocks);
+// the settled-chain kernel (pmdi_sweep2.hip)
+void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, S2Layout *L);
+bool pmdi_sweep2_supports(int K, int N, int P, int Dmax, long long cap);
+hipError_t pmdi_sweep2_blocks_per_cu(const SweepArgs &a, int *blocks);
+hipError_t pmdi_launch_sweep2(const SweepArgs &a, SweepArgs *d_args, int n_chains, hipStream_t stream, SweepArgs *staging = nullptr);
 hipError_t pmdi_launch_cluster_add(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logprob(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_t stream);

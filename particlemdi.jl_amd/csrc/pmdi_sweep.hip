@@ -1336,6 +1336,7 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
                 st[ST_MAXID] = sh.stat[3]; st[ST_SUMCLASSES] = sh.stat[4];
                 st[5] = sh.stat[5]; st[6] = sh.stat[6]; st[7] = sh.stat[7];
                 if (!a.err_keep) a.err[chain] = 0;
+                if (a.requeue) a.requeue[chain] = 0;
             } else {
                 // the K workgroups of the chain add their datasets' counters (the host zeroed stats and err before the launch)
                 if (kd0 == 0) { a.pstar[chain] = pstar; st[ST_NRESAMPLE] = sh.stat[1]; }
@@ -1366,6 +1367,8 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     if (bslot >= a.n_slots) return;            // padding of a split launch (chain slots are dealt in groups of eight)
     // two launches share the chains of a sweep (heavy: wide workgroups, light: narrow ones)
     if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || bslot < a.rank_lo || bslot >= a.rank_hi)) return;
+    // ... or this launch sweeps exactly the chains the settled-chain kernel (pmdi_sweep2.hip) gave back
+    if (a.requeue_only && !a.requeue[chain]) return;
     // hand-off area of the split mode: per (chain, parity of the swept observation, dataset): the log-weight increment and
     // the chosen label of every particle; one arrival counter per chain
     // (the addresses are rebuilt from the argument block where they are used: nothing of this stays live across the step loop)

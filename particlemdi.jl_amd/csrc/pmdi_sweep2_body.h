@@ -62,7 +62,14 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
 #define PM2_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PM2_UNI(x) __builtin_amdgcn_readfirstlane(x)
 #define PM2_CLOCK() ((long long)clock64())
-#define PM2_G(T, p) ((__attribute__((address_space(1))) T *)(p))
+// arena / argument pointers are global memory: say so where they are formed (global_* instead of flat_* instructions; the
+// address-space inference carries it through the generic pointers they are assigned to).  The host pass of a HIP compile only
+// parses the device code: no address spaces there.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PM2_G(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
+#else
+#define PM2_G(T, p) ((T *)(p))
+#endif
 __device__ __forceinline__ unsigned long long pm2_shfl64(unsigned long long v, int src)
 {
     const int lo = __shfl((int)(unsigned)v, src), hi = __shfl((int)(unsigned)(v >> 32), src);
@@ -107,7 +114,7 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     auto take = [&](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };
     const int Dp = (Dmax + 1) & ~1;
     L.Dp = Dp; L.cols_l = cols_l; L.idcap = idcap;
-    L.red = take(64 * 8);
+    L.red = take(128 * 8);       // reductions: [0,8) maxima, [8,16) sums, [16,32) integer scratch, [64,112) replay stacks, [120] tie
     L.sc = take(SC_COUNT * 4);
     L.stat = take(8 * 8);
     L.wk = take(KMAX2 * 8 * 8);
@@ -243,7 +250,9 @@ template <int K, int PPL>
 struct Sweep2 {
     // ---- per-lane state ----
     double lw[PPL];
-    int col[K][PPL], csl[K][PPL];
+    static constexpr int NCP = (PPL + 1) / 2;
+    unsigned colp[K][NCP];      // column index of the lane's particles per dataset, 16 bits each
+    unsigned cslp;              // class slot of the lane's particles per dataset, 2 bits each: bit offset 2 * (k * PPL + u)
     double c_mu[NS], c_lam[NS], c_sg[NS], c_bt[NS];     // owner wave: the cluster cache of its dataset, lane = feature
     // ---- uniform ----
     const SweepArgs *ap;
@@ -254,6 +263,32 @@ struct Sweep2 {
     long long n, n1;
 
 #define L (ap->s2)
+    // the packed registers are only ever indexed by compile-time constants: a run-time dataset index goes through these selects
+    PM2_DEV void col_get(int k, int (&ck)[PPL]) const
+    {
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            if (kk == k) {
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) ck[u] = (int)((colp[kk][u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+            }
+    }
+    PM2_DEV void col_put(int k, const int (&ck)[PPL])
+    {
+        unsigned pk[NCP];
+#pragma unroll
+        for (int j = 0; j < NCP; ++j) pk[j] = 0;
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) pk[u >> 1] |= (unsigned)ck[u] << ((u & 1) * 16);
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk)
+            if (kk == k) {
+#pragma unroll
+                for (int j = 0; j < NCP; ++j) colp[kk][j] = pk[j];
+            }
+    }
+    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp >> (2 * (k * PPL + u))) & 3u); }
+    PM2_DEV void csl_put(int k, int u, int r) { const int sh = 2 * (k * PPL + u); cslp = (cslp & ~(3u << sh)) | ((unsigned)r << sh); }
     PM2_DEV DV view(int k) const
     {
         DV v;
@@ -848,7 +883,7 @@ struct Sweep2 {
         if (tid == 0) {
             // carries: replay the recursion over the leaf totals (program built at kernel start: op 0 = leaf, 3 = descend left,
             // 1 = left done -> right child's carry, 2 = node done); leaf l's total sits at its LAST block
-            double cs[24], lt[24];
+            double *cs = lds<double>(L.red) + 64, *lt = lds<double>(L.red) + 88;      // (stacks of the replay: LDS, not scratch)
             int sp = 0;
             cs[0] = w[0];
             double ret = 0.0;
@@ -879,8 +914,11 @@ struct Sweep2 {
     }
 
     // ---- draw_partstar + gather + compact renumbering (src/misc.jl:27-47, src/pmdi.jl:318-340) ---------------------------------------
-    PM2_DEV void resample(long long pos, const double (&w)[PPL])
+    PM2_DEV void resample(long long pos, double mx)
     {
+        double w[PPL];
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) w[u] = exp(lw[u] - mx);        // pprob before the cumsum (src/misc.jl:29), as calc_ESS formed it
         const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
         const double usl = pmdi_arith::uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
         double c[PPL];
@@ -956,27 +994,32 @@ struct Sweep2 {
         u16 *scol = lds<u16>(L.tr), *mult = lds<u16>(L.tr + P * 2), *cmap = lds<u16>(L.tr + P * 4);
         u8 *scsl = lds<u8>(L.tr + P * 6);
         int *hist = lds<int>(L.tr + L.rs_hist);
+#pragma nounroll
         for (int k = 0; k < K; ++k) {
             const DV v = view(k);
             int *dsc = v.dsc();
             const int ncol_old = dsc[DS_NCOL], oldmax = dsc[DS_MAXID], ncls_old = dsc[DS_NCLS];
+            int ck[PPL], rk[PPL];                           // this dataset's column / class slot of the lane's particles
+            col_get(k, ck);
 #pragma unroll
-            for (int uu = 0; uu < PPL; ++uu) { const int p = tid * PPL + uu; scol[p] = (u16)col[k][uu]; scsl[p] = (u8)csl[k][uu]; }
+            for (int uu = 0; uu < PPL; ++uu) rk[uu] = csl_get(k, uu);
+#pragma unroll
+            for (int uu = 0; uu < PPL; ++uu) { const int p = tid * PPL + uu; scol[p] = (u16)ck[uu]; scsl[p] = (u8)rk[uu]; }
             for (int e = tid; e < ncol_old; e += T) mult[e] = 0;
             for (int e = tid; e <= oldmax && e < v.idcap; e += T) hist[e] = 0;
-            if (tid < CLS) lds<int>(L.red)[16 + tid] = 0x7fffffff;
+            if (tid < CLS) lds<int>(L.red)[36 + tid] = 0x7fffffff;
             PM2_BARRIER();
             // particle[:, partstar, k], particle_id[partstar, k] (:322-323): a particle takes its ancestor's column index and class
 #pragma unroll
             for (int uu = 0; uu < PPL; ++uu) {
                 const int p = tid * PPL + uu;
                 const int an = anc[p];
-                col[k][uu] = scol[an]; csl[k][uu] = scsl[an];
+                ck[uu] = scol[an]; rk[uu] = scsl[an];
             }
 #pragma unroll
             for (int uu = 0; uu < PPL; ++uu) {
                 // particles per old column, aggregated over the lanes that took the same one
-                const int cl = col[k][uu];
+                const int cl = ck[uu];
                 u64 rem = ~0ull;
                 while (rem) {
                     const int l0 = pm2_ffs64(rem) - 1;
@@ -990,10 +1033,10 @@ struct Sweep2 {
                     rem &= ~m;
                 }
                 // lowest particle of every class
-                const int r = csl[k][uu];
+                const int r = rk[uu];
                 for (int rr = 0; rr < ncls_old; ++rr) {
                     const u64 m = PM2_BALLOT(r == rr);
-                    if (m && lane == pm2_ffs64(m) - 1) pm2_atomic_min(&lds<int>(L.red)[16 + rr], tid * PPL + uu);
+                    if (m && lane == pm2_ffs64(m) - 1) pm2_atomic_min(&lds<int>(L.red)[36 + rr], tid * PPL + uu);
                 }
             }
             PM2_BARRIER();
@@ -1003,10 +1046,10 @@ struct Sweep2 {
                 const int cc = b + tid;
                 const bool live = cc < ncol_old && mult[cc] != 0;
                 const u64 bal = PM2_BALLOT(live);
-                if (lane == 0) lds<int>(L.red)[32 + wave] = pm2_popc64(bal);
+                if (lane == 0) lds<int>(L.red)[48 + wave] = pm2_popc64(bal);
                 PM2_BARRIER();
                 int basew = ncol_new, tot = 0;
-                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[32 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
+                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[48 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
                 if (live) cmap[cc] = (u16)(basew + pm2_popc64(bal & ((1ull << lane) - 1ull)));
                 ncol_new += tot;
                 PM2_BARRIER();
@@ -1017,7 +1060,7 @@ struct Sweep2 {
                 const int m = mult[cc];
                 if (m) {
                     const int id = v.tab_get(cc, idx - cc * N);
-                    if (id < v.idcap) pm2_atomic_add(&hist[id], m); else pm2_atomic_add(PM2_G(int, v.ar.ncop()) + id, m);
+                    if (id < v.idcap) pm2_atomic_add(&hist[id], m); else pm2_atomic_add(v.ar.ncop() + id, m);
                 }
             }
             PM2_BARRIER();
@@ -1029,10 +1072,10 @@ struct Sweep2 {
                 if (id <= oldmax) occ = (id < v.idcap) ? hist[id] : PM2_G(int, v.ar.ncop())[id];
                 const bool live = occ != 0;
                 const u64 bal = PM2_BALLOT(live);
-                if (lane == 0) lds<int>(L.red)[32 + wave] = pm2_popc64(bal);
+                if (lane == 0) lds<int>(L.red)[48 + wave] = pm2_popc64(bal);
                 PM2_BARRIER();
                 int basew = newmax, tot = 0;
-                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[32 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
+                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[48 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
                 if (id <= oldmax) *v.tgt_p(id) = live ? basew + pm2_popc64(bal & ((1ull << lane) - 1ull)) + 1 : 0;
                 newmax += tot;
                 PM2_BARRIER();
@@ -1106,7 +1149,7 @@ struct Sweep2 {
                 }
             }
 #pragma unroll
-            for (int uu = 0; uu < PPL; ++uu) col[k][uu] = cmap[col[k][uu]];
+            for (int uu = 0; uu < PPL; ++uu) ck[uu] = cmap[ck[uu]];
             // classes that kept a particle, in leader order; leaders' columns
             {
                 int *redi = lds<int>(L.red);
@@ -1115,9 +1158,9 @@ struct Sweep2 {
 #pragma unroll
                 for (int r = 0; r < CLS; ++r) {
                     newslot[r] = -1;
-                    if (r < ncls_old && redi[16 + r] != 0x7fffffff) {
+                    if (r < ncls_old && redi[36 + r] != 0x7fffffff) {
                         int s = 0;
-                        for (int r2 = 0; r2 < ncls_old; ++r2) if (redi[16 + r2] < redi[16 + r]) ++s;
+                        for (int r2 = 0; r2 < ncls_old; ++r2) if (redi[36 + r2] < redi[36 + r]) ++s;
                         newslot[r] = s;
                         nc2 += 1;
                     }
@@ -1129,15 +1172,18 @@ struct Sweep2 {
 #pragma unroll
                 for (int uu = 0; uu < PPL; ++uu) {
                     const int p = tid * PPL + uu;
-                    const int r = csl[k][uu];
-                    int ns_ = 0;
+                    const int r = rk[uu];
+                    int ns_ = 0, cvr = 0;
 #pragma unroll
-                    for (int r2 = 0; r2 < CLS; ++r2) if (r2 == r) ns_ = newslot[r2];
-                    csl[k][uu] = ns_;
-                    if (redi[16 + r] == p) {
-                        lds<int>(v.base + L.clsval)[ns_] = cv[r]; lds<int>(v.base + L.clslead)[ns_] = p; lds<int>(v.base + L.leadcol)[ns_] = col[k][uu];
+                    for (int r2 = 0; r2 < CLS; ++r2) if (r2 == r) { ns_ = newslot[r2]; cvr = cv[r2]; }
+                    rk[uu] = ns_;
+                    if (redi[36 + r] == p) {
+                        lds<int>(v.base + L.clsval)[ns_] = cvr; lds<int>(v.base + L.clslead)[ns_] = p; lds<int>(v.base + L.leadcol)[ns_] = ck[uu];
                     }
                 }
+                col_put(k, ck);
+#pragma unroll
+                for (int uu = 0; uu < PPL; ++uu) csl_put(k, uu, rk[uu]);
                 if (tid == 0) {
                     const int moved = sc()[SC_TMP0];
                     dsc[DS_NCLS] = nc2; dsc[DS_NCOL] = ncol_new; dsc[DS_MAXID] = newmax;
@@ -1168,7 +1214,7 @@ struct Sweep2 {
         if (tid == 0) {
             // leaf decomposition of Julia's accumulate_pairwise! over [1, P) and its recursion as a post-order program
             int nl = 0, np = 0, sp = 0;
-            int st_i1[24], st_n[24], st_stage[24];
+            int *st_i1 = lds<int>(L.tr), *st_n = st_i1 + 24, *st_stage = st_i1 + 48;      // (the recursion's stack: LDS, not scratch)
             int *li1 = lds<int>(L.leaf_i1), *ln = lds<int>(L.leaf_n);
             u8 *prog = lds<u8>(L.leaf_prog);
             st_i1[0] = 1; st_n[0] = P - 1; st_stage[0] = 0;
@@ -1186,7 +1232,8 @@ struct Sweep2 {
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int u = 0; u < PPL; ++u) { col[k][u] = 0; csl[k][u] = 0; }
+            for (int j = 0; j < NCP; ++j) colp[k][j] = 0;
+        cslp = 0;
 #pragma unroll
         for (int s = 0; s < NS; ++s) { c_mu[s] = 0.0; c_lam[s] = 1.0; c_sg[s] = 0.0; c_bt[s] = 0.5; }
         PM2_BARRIER();
@@ -1210,16 +1257,20 @@ struct Sweep2 {
             PM2_BARRIER();
             if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
             // ---- particle phase (all lanes, all datasets): allocation draw (:251-265), census, weights (:227,:245), Phi (:312-314)
-            int ns_[K][PPL], cc_[K][PPL];
+            unsigned nsp[PPL];                                                  // the labels a particle drew, a byte per dataset
 #pragma unroll
+            for (int u = 0; u < PPL; ++u) nsp[u] = 0;
+#pragma nounroll
             for (int k = 0; k < K; ++k) {
                 const DV v = view(k);
                 const int ns0 = v.dsc()[DS_NS0];
+                int ck[PPL];
+                col_get(k, ck);
                 unsigned packed = 0;
 #pragma unroll
                 for (int u = 0; u < PPL; ++u) {
                     const int p = tid * PPL + u;
-                    const int r = csl[k][u];
+                    const int r = csl_get(k, u);
                     const double *row = v.cdf_row(r);
                     const int hot = (int)row[N + 1];
                     int ns = 0;
@@ -1231,8 +1282,8 @@ struct Sweep2 {
                         for (int t = 0; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
                     }
                     lw[u] = lw[u] + row[N];                                     // logweight[p] += increment (:227,:245), dataset order
-                    const int c = v.tab_get(col[k][u], ns);                     // sstar_id (:264)
-                    ns_[k][u] = ns; cc_[k][u] = c;
+                    const int c = v.tab_get(ck[u], ns);                         // sstar_id (:264)
+                    nsp[u] |= (unsigned)ns << (8 * k);
                     packed |= (unsigned)ns << (8 * (u & 3));
                     if ((u & 3) == 3 || u == PPL - 1) {                         // sstar[p, i, k] (:265), four particles per store
                         u8 *ss = v.ar.sstar() + (size_t)pos * P + (size_t)tid * PPL + (u & ~3);
@@ -1241,7 +1292,7 @@ struct Sweep2 {
                         else *PM2_G(u8, ss) = (u8)packed;
                         packed = 0;
                     }
-                    census(v, r, col[k][u], ns, c, p);
+                    census(v, r, ck[u], ns, c, p);
                 }
             }
             if (K > 1) {                                                        // Phi_upweight! (src/misc.jl:50-59)
@@ -1252,7 +1303,10 @@ struct Sweep2 {
 #pragma unroll
                     for (int k1 = 0; k1 < K - 1; ++k1)
 #pragma unroll
-                        for (int k2 = k1 + 1; k2 < K; ++k2) { wv_ += (ns_[k1][u] == ns_[k2][u]) ? logphi[pr] : 0.0; ++pr; }
+                        for (int k2 = k1 + 1; k2 < K; ++k2) {
+                            wv_ += (((nsp[u] >> (8 * k1)) & 0xffu) == ((nsp[u] >> (8 * k2)) & 0xffu)) ? logphi[pr] : 0.0;
+                            ++pr;
+                        }
                     lw[u] = wv_;
                 }
             }
@@ -1266,13 +1320,12 @@ struct Sweep2 {
             }
             PM2_BARRIER();
             // ---- calc_ESS (src/misc.jl:15-25), first half; the bookkeeping phase of the owner waves
-            double w[PPL];
             double mx = red[0];
             for (int w_ = 1; w_ < T / 64; ++w_) mx = (red[w_] > mx) ? red[w_] : mx;
             {
                 double sa = 0.0, sq = 0.0;
 #pragma unroll
-                for (int u = 0; u < PPL; ++u) { w[u] = exp(lw[u] - mx); sa += w[u]; sq += w[u] * w[u]; }
+                for (int u = 0; u < PPL; ++u) { const double w = exp(lw[u] - mx); sa += w; sq += w * w; }
                 sa = wave_sum_d(sa); sq = wave_sum_d(sq);
                 if (lane == 0) { red[8 + wave] = sa; red[12 + wave] = sq; }
             }
@@ -1280,21 +1333,24 @@ struct Sweep2 {
             PM2_BARRIER();
             if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
             // ---- every particle follows its group: new column, new class slot
-#pragma unroll
+#pragma nounroll
             for (int k = 0; k < K; ++k) {
                 const DV v = view(k);
+                int ck[PPL];
+                col_get(k, ck);
 #pragma unroll
                 for (int u = 0; u < PPL; ++u) {
-                    const int cl = col[k][u], ns = ns_[k][u];
+                    const int cl = ck[u], ns = (int)((nsp[u] >> (8 * k)) & 0xffu);
                     const u64 wm = *v.wmask_p(cl);
                     if ((wm >> ns) & 1ull) {
                         const int bi = *v.cbi_p(cl);
                         const int inpl = (bi & 0xff) - 1, base = bi >> 8;
                         const int rnk = pm2_popc64(wm & ((1ull << ns) - 1ull));
-                        col[k][u] = (inpl >= 0) ? (ns == inpl ? cl : base + rnk - 1) : base + rnk;
+                        ck[u] = (inpl >= 0) ? (ns == inpl ? cl : base + rnk - 1) : base + rnk;
                     }
-                    csl[k][u] = lds<u8>(v.base + L.knew)[csl[k][u] * N + ns];
+                    csl_put(k, u, (int)lds<u8>(v.base + L.knew)[csl_get(k, u) * N + ns]);
                 }
+                col_put(k, ck);
             }
             double sa = 0.0, sq = 0.0;
             for (int w_ = 0; w_ < T / 64; ++w_) { sa += red[8 + w_]; sq += red[12 + w_]; }
@@ -1306,21 +1362,21 @@ struct Sweep2 {
                 double *wt = lds<double>(L.tr);
                 PM2_BARRIER();
 #pragma unroll
-                for (int u = 0; u < PPL; ++u) wt[tid * PPL + u] = w[u];
+                for (int u = 0; u < PPL; ++u) wt[tid * PPL + u] = exp(lw[u] - mx);
                 PM2_BARRIER();
                 if (tid == 0) {
                     double na = 0.0, nb = 0.0;
                     for (int p = 0; p < P; ++p) { na += wt[p]; nb += wt[p] * wt[p]; }
-                    red[40] = (na * na) / nb;
+                    red[120] = (na * na) / nb;
                 }
                 PM2_BARRIER();
-                ess = red[40];
+                ess = red[120];
                 PM2_BARRIER();
             }
             const bool res = ess <= 0.5 * (double)P;              // src/pmdi.jl:317
             if (res) {
                 if (tid == 0) stat()[1] += 1;
-                resample(pos, w);
+                resample(pos, mx);
             }
             if (a.trace_on && tid == 0) {
                 double *tr = PM2_G(double, a.trace) + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
@@ -1330,7 +1386,12 @@ struct Sweep2 {
         }
         if (failed) {
             if (tid == 0) {
-                PM2_G(int, a.err)[chain] = (failed == 1) ? -4 : PMDI_S2_REQUEUE;          // PMDI_E_POOL / sweep again with the general kernel
+                if (failed == 1) PM2_G(int, a.err)[chain] = -4;                            // PMDI_E_POOL
+                else if (a.requeue) {
+                    PM2_G(int, a.requeue)[chain] = 1;                                      // sweep again with the general kernel
+                    if (a.requeue_total) { pm2_atomic_add((u64 *)a.requeue_total + 3, (u64)1); pm2_atomic_add((u64 *)a.requeue_total + (failed - 2), (u64)1); }
+                }
+                else PM2_G(int, a.err)[chain] = PMDI_S2_REQUEUE;                           // (no requeue list: report it)
                 PM2_G(long long, a.stats)[(size_t)chain * 8 + 7] = failed;                // (why: 2 reachable clusters, 3 chosen clusters, 4 classes)
                 PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
             }
@@ -1389,14 +1450,17 @@ struct Sweep2 {
 #pragma unroll
             for (int u = 0; u < PPL; ++u) PM2_G(double, a.lw_out)[(size_t)chain * P + tid * PPL + u] = lw[u];
         // what pmdi_export_state reads: the columns, the column and class of every particle, counts, cluster sizes
+#pragma nounroll
         for (int k = 0; k < K; ++k) {
             const DV v = view(k);
             const int ncol = v.dsc()[DS_NCOL], maxid = v.dsc()[DS_MAXID];
             int *tg = PM2_G(int, v.ar.tabg());
             for (int e = tid; e < ncol * N && e < v.cols_l * N; e += T) tg[e] = (int)lds<u16>(v.base + L.tab)[e];
             int *cg = PM2_G(int, v.ar.colg()), *pg = PM2_G(int, v.ar.pidg());
+            int ck[PPL];
+            col_get(k, ck);
 #pragma unroll
-            for (int u = 0; u < PPL; ++u) { cg[tid * PPL + u] = col[k][u]; pg[tid * PPL + u] = lds<int>(v.base + L.clsval)[csl[k][u]]; }
+            for (int u = 0; u < PPL; ++u) { cg[tid * PPL + u] = ck[u]; pg[tid * PPL + u] = lds<int>(v.base + L.clsval)[csl_get(k, u)]; }
             int *cng = PM2_G(int, v.ar.cn()), *ctg = PM2_G(int, v.ar.counts());
             for (int id = tid; id < v.idcap && id <= a.cap; id += T) { cng[id] = (id <= maxid) ? lds<int>(v.base + L.cn)[id] : cng[id]; ctg[id] = (id <= maxid) ? lds<int>(v.base + L.counts)[id] : 0; }
             for (int id = maxid + 1 + tid; id <= a.cap; id += T) ctg[id] = 0;
@@ -1412,6 +1476,7 @@ struct Sweep2 {
             st[ST_NOPS] = s[0]; st[ST_NRESAMPLE] = s[1]; st[ST_NCLONES] = s[2]; st[ST_MAXID] = s[3]; st[ST_SUMCLASSES] = s[4];
             st[5] = s[5]; st[6] = 0; st[7] = 0;
             if (!a.err_keep) PM2_G(int, a.err)[chain] = 0;
+            if (a.requeue) PM2_G(int, a.requeue)[chain] = 0;
             PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
         }
         if (a.work && tid < K * 8) PM2_G(long long, a.work)[((size_t)chain * PMDI_KMAX_I) * 8 + tid] = lds<long long>(L.wk)[tid];

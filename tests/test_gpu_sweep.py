@@ -304,3 +304,66 @@ def test_split_form_stops_all_partners_when_one_runs_out_of_pool(pkg, monkeypatc
     assert e.value.code == -4                         # PMDI_E_POOL
     assert time.perf_counter() - t0 < 10.0            # ... not the watchdog
     sw.close()
+
+
+def _gauss_planted(rng, n, K, D=12, sep=3.0):
+    z = rng.integers(0, 3, n)
+    return [rng.normal(size=(n, D + k)) + sep * (z[:, None] - 1) for k in range(K)], z
+
+
+@pytest.mark.parametrize("K,P,n,N", [(1, 256, 300, 6), (2, 512, 300, 8), (4, 1024, 400, 10), (3, 256, 240, 20)])
+def test_settled_chain_kernel_equals_oracle(pkg, O, monkeypatch, K, P, n, N):
+    """The settled-chain kernel (csrc/pmdi_sweep2.hip) on chains that look settled -- the planted clustering with a few labels
+    scrambled --, forced from the first sweep (PMDI_SETTLED=2; a chain whose step outgrows its tables is handed back to the general
+    kernel inside the same sweep: same results either way): trace, allocations, picked particle, log-weights, counters, work
+    counters and the exported state equal the oracle's."""
+    monkeypatch.setenv("PMDI_SETTLED", "2")
+    rng = np.random.default_rng(100 + K)
+    data, z = _gauss_planted(rng, n, K)
+    kinds = ["gaussian"] * K
+    n1 = n // 4
+    C = 3
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=C, seed=900)
+    assert sw.settled
+    orcs = [O.Oracle(data, kinds, N, P, seed=900 + c) for c in range(C)]
+    recs = [o.debug_steps(n - n1 + 1) for o in orcs]
+    s = np.repeat(np.repeat((z + 1)[None, :, None], K, axis=2), C, axis=0)
+    idx = rng.random(s.shape) < 0.04
+    s[idx] = rng.integers(1, N + 1, size=int(idx.sum()))
+    for it in range(1, 4):
+        order = np.stack([rng.permutation(n) + 1 for _ in range(C)])
+        hyp = [random_hypers(rng, N, K) for _ in range(C)]
+        for h in hyp:
+            h[0][:3] += 1.0; h[0][:] = h[0] / h[0].sum(0)
+        rg = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]), trace=True)
+        wk = sw.work_counters()
+        for c in range(C):
+            ro = orcs[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1], trace=True)
+            bad = np.where(~np.isclose(rg["trace"][c], ro["trace"], rtol=1e-9, atol=1e-9).all(axis=1))[0]
+            assert bad.size == 0, f"chain {c} iteration {it}: first diverging swept observation {bad[0]}: gpu={rg['trace'][c][bad[0]]} cpu={ro['trace'][bad[0]]}"
+            assert (rg["s"][c] == ro["s"]).all() and int(rg["p_star"][c]) == ro["p_star"]
+            assert np.allclose(rg["logweight"][c], ro["logweight"], rtol=1e-9, atol=1e-8)
+            for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
+                assert rg["stats"][c][key] == ro["stats"][key], key
+            up, mv = orcs[c].work()
+            ev, cols, splits = expected_work_counters(recs[c], ro["trace"], N)
+            assert (wk[c][:, 1] == up).all() and (wk[c][:, 3] == mv).all() and (wk[c][:, 0] == ev).all()
+            assert (wk[c][:, 5] == cols).all() and (wk[c][:, 6] == splits).all()
+            eg, eo = sw.export_state(c), orcs[c].export()
+            assert (eg["particle"] == eo["particle"]).all() and (eg["max_id"] == eo["max_id"]).all()
+            t5_invariants(eg, N, P, K, n)
+            s[c] = ro["s"]
+    gb = sw.given_back()
+    print(f"K={K} P={P}: chains handed back to the general kernel (reachable, chosen, classes, total) = {gb.tolist()} of {3 * C} chain-sweeps")
+    assert gb[3] <= 2 * C          # most of these sweeps fit the settled-chain kernel (the hand-back path is exercised, not the norm)
+    sw.close()
+
+
+def test_settled_chain_kernel_hands_back_what_does_not_fit(pkg, O, monkeypatch):
+    """From the random start of src/pmdi.jl:63-66 a chain has dozens of particle classes: forced onto the settled-chain kernel it is
+    handed back at once and the general kernel sweeps it: results equal the oracle's, and the counter of handed-back chains moves."""
+    monkeypatch.setenv("PMDI_SETTLED", "2")
+    rng = np.random.default_rng(77)
+    data, _ = _gauss_planted(rng, 200, 2, sep=1.0)
+    g = _compare_run(pkg, O, data, ["gaussian"] * 2, 8, 256, 2, 78, 50)
+    assert g.sw.settled and g.sw.given_back()[3] >= 1
