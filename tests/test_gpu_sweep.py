@@ -318,6 +318,7 @@ def test_settled_chain_kernel_equals_oracle(pkg, O, monkeypatch, K, P, n, N):
     kernel inside the same sweep: same results either way): trace, allocations, picked particle, log-weights, counters, work
     counters and the exported state equal the oracle's."""
     monkeypatch.setenv("PMDI_SETTLED", "2")
+    monkeypatch.setenv("PMDI_KSPLIT", "0")          # (a small batch with K > 1 would default to K workgroups per chain)
     rng = np.random.default_rng(100 + K)
     data, z = _gauss_planted(rng, n, K)
     kinds = ["gaussian"] * K
@@ -363,6 +364,7 @@ def test_settled_chain_kernel_hands_back_what_does_not_fit(pkg, O, monkeypatch):
     """From the random start of src/pmdi.jl:63-66 a chain has dozens of particle classes: forced onto the settled-chain kernel it is
     handed back at once and the general kernel sweeps it: results equal the oracle's, and the counter of handed-back chains moves."""
     monkeypatch.setenv("PMDI_SETTLED", "2")
+    monkeypatch.setenv("PMDI_KSPLIT", "0")
     rng = np.random.default_rng(77)
     data, _ = _gauss_planted(rng, 200, 2, sep=1.0)
     g = _compare_run(pkg, O, data, ["gaussian"] * 2, 8, 256, 2, 78, 50)
