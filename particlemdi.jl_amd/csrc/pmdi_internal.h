@@ -73,7 +73,7 @@ struct DsetDev {
 // LDS layout of the settled-chain kernel (pmdi_sweep2_body.h: make_layout fills it on the host, the kernel reads it from the
 // argument block): byte offsets into the workgroup's LDS
 struct S2Layout {
-    int red, sc, stat, wk, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, xfl;
+    int red, sc, stat, wk, ph, leaf_i1, leaf_n, leaf_tot, leaf_carry, leaf_prog, xfl;
     int tr, tr_stride, tr_tb, tr_cdf, tr_bytes;       // transient region: per dataset tb rows + CDF rows; aliased by the resampling scratch
     int rs_jtab, rs_raw, rs_anc, rs_hist;             // resampling scratch inside the transient region
     int ds0, ds_stride;                               // dataset blocks

@@ -42,6 +42,9 @@
 #define PM2_UNI(x) (x)
 #define PM2_CLOCK() (0ll)
 #define PM2_G(T, p) ((T *)(p))
+#define PM2_CONST
+#define PM2_LAUNDER(ptr_, T) do { } while (0)
+#define PM2_FRESH_VGPR(x_) do { } while (0)
 template <class T> inline T pm2_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
 template <class T> inline T pm2_atomic_min(T *p, T v) { const T o = *p; if (v < o) *p = v; return o; }
 template <class T> inline T pm2_atomic_or(T *p, T v) { const T o = *p; *p = o | v; return o; }
@@ -62,13 +65,28 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
 #define PM2_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PM2_UNI(x) __builtin_amdgcn_readfirstlane(x)
 #define PM2_CLOCK() ((long long)clock64())
-// arena / argument pointers are global memory: say so where they are formed (global_* instead of flat_* instructions; the
-// address-space inference carries it through the generic pointers they are assigned to).  The host pass of a HIP compile only
-// parses the device code: no address spaces there.
+// arena / argument pointers are global memory: PM2_G types them so (global_* instead of flat_* instructions); what holds one is
+// declared `auto` (a generic pointer variable would drop the address space again).  The host pass of a HIP compile only parses the
+// device code: no address spaces there.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define PM2_G(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
+#define PM2_G(T, p) ((__attribute__((address_space(1))) T *)(p))
+// the argument block is read through the constant address space (s_load, never a vector load); once per swept observation its
+// address is passed through an empty asm: what is derived from it (array addresses of K datasets, LDS offsets) is then rebuilt
+// from scalar loads where it is used instead of being hoisted out of the sweep loop into registers that do not exist
+#define PM2_CONST __attribute__((address_space(4)))
+#define PM2_LAUNDER(ptr_, T)                                                                                                      \
+    do {                                                                                                                          \
+        const unsigned long long v_ = (unsigned long long)(ptr_);                                                                 \
+        unsigned lo_ = (unsigned)v_, hi_ = (unsigned)(v_ >> 32);                                                                  \
+        asm volatile("" : "+s"(lo_), "+s"(hi_));                                                                                  \
+        (ptr_) = (const PM2_CONST T *)(((unsigned long long)hi_ << 32) | (unsigned long long)lo_);                               \
+    } while (0)
+#define PM2_FRESH_VGPR(x_) asm volatile("" : "+v"(x_))
 #else
 #define PM2_G(T, p) ((T *)(p))
+#define PM2_CONST
+#define PM2_LAUNDER(ptr_, T) do { } while (0)
+#define PM2_FRESH_VGPR(x_) do { } while (0)
 #endif
 __device__ __forceinline__ unsigned long long pm2_shfl64(unsigned long long v, int src)
 {
@@ -102,7 +120,7 @@ constexpr unsigned INFU = 0xFFFFFFFFu;
 constexpr int PMDI_S2_REQUEUE = 1;   // err code: sweep this chain again with the general kernel
 
 // per-dataset scalars (ints in LDS)
-enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_ND, DS_NK, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_SLOTFREE, DS_COUNT = 16 };
+enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_ND, DS_NK, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_FOLLOW, DS_DIRTY, DS_NEEDMASK, DS_CHANGED, DS_COUNT = 16 };
 // shared scalars
 enum { SC_FAIL = 0, SC_RES, SC_PSTAR, SC_NLEAF, SC_NPROG, SC_JS, SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3, SC_COUNT = 16 };
 
@@ -118,6 +136,7 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     L.sc = take(SC_COUNT * 4);
     L.stat = take(8 * 8);
     L.wk = take(KMAX2 * 8 * 8);
+    L.ph = take(16 * 8);
     L.leaf_i1 = take(64 * 4); L.leaf_n = take(64 * 4); L.leaf_tot = take(64 * 8); L.leaf_carry = take(64 * 8); L.leaf_prog = take(256);
     L.xfl = take(KMAX2 * 64);                                   // feature flags per dataset (bytes)
     // transient region
@@ -158,7 +177,7 @@ template <class Tp> PM2_DEV Tp *lds(int off) { return (Tp *)(PM2_SMEM + off); }
 
 struct Arena {   // the chain's arrays of one dataset in global memory (what exceeds the LDS tables; the pool; the history)
     char *b;
-    const DsetDev *d;
+    const PM2_CONST DsetDev *d;
     PM2_DEV int *tabg() const { return (int *)(b + d->o_particle[0]); }
     PM2_DEV int *colg() const { return (int *)(b + d->o_col); }
     PM2_DEV int *pidg() const { return (int *)(b + d->o_pid); }
@@ -177,25 +196,36 @@ struct DV {      // view of one dataset: LDS block + arena
     int base;            // LDS offset of the dataset block
     int trb;             // LDS offset of its transient rows
     int N, P, D, Dp, cols_l, idcap;
-    const Layout *lay;
+    const PM2_CONST Layout *lay;
     Arena ar;
     PM2_DEV int *dsc() const { return lds<int>(base + lay->dsc); }
     // particle[label, column]: the distinct columns of particle[:, :, k]
-    PM2_DEV int tab_get(int c, int nn) const { return c < cols_l ? (int)lds<u16>(base + lay->tab)[c * N + nn] : PM2_G(int, ar.tabg())[(size_t)c * N + nn]; }
+    PM2_DEV int tab_get(int c, int nn) const
+    {
+        if (c < cols_l) return (int)lds<u16>(base + lay->tab)[c * N + nn];
+        return PM2_G(int, ar.tabg())[(size_t)c * N + nn];
+    }
     PM2_DEV void tab_set(int c, int nn, int v) const
     {
         if (c < cols_l) lds<u16>(base + lay->tab)[c * N + nn] = (u16)v; else PM2_G(int, ar.tabg())[(size_t)c * N + nn] = v;
     }
-    // per-column tables
-    PM2_DEV u64 *cmask_p(int c) const { return c < cols_l ? lds<u64>(base + lay->cmask) + c : ar.cmeta() + c; }
-    PM2_DEV u64 *wmask_p(int c) const { return c < cols_l ? lds<u64>(base + lay->wmask) + c : ar.cmeta() + P + c; }
-    PM2_DEV int *cbi_p(int c) const { return c < cols_l ? lds<int>(base + lay->cbi) + c : (int *)(ar.cmeta() + 2 * (size_t)P) + c; }
-    // per-id tables
-    PM2_DEV int *counts_p(int id) const { return id < idcap ? lds<int>(base + lay->counts) + id : ar.counts() + id; }
-    PM2_DEV int *cn_p(int id) const { return id < idcap ? lds<int>(base + lay->cn) + id : ar.cn() + id; }
-    PM2_DEV int *ncop_p(int id) const { return id < idcap ? lds<int>(base + lay->ncop) + id : ar.ncop() + id; }
-    PM2_DEV int *firstp_p(int id) const { return id < idcap ? lds<int>(base + lay->firstp) + id : ar.firstp() + id; }
-    PM2_DEV int *tgt_p(int id) const { return id < idcap ? lds<int>(base + lay->tgt) + id : ar.tgt() + id; }
+    // per-column and per-id tables: direct-indexed, the first cols_l columns / idcap ids in LDS, the rest in the chain's arena.  Every
+    // access is an explicit branch between a typed LDS and a typed global access (a pointer select would make it a flat_* instruction)
+#define PM2_TABLE(name, Tp, cap, ldsoff, gexpr)                                                                                   \
+    PM2_DEV Tp name##_get(int i) const { if (i < cap) return lds<Tp>(base + lay->ldsoff)[i]; return PM2_G(Tp, gexpr)[i]; }          \
+    PM2_DEV void name##_set(int i, Tp x) const { if (i < cap) lds<Tp>(base + lay->ldsoff)[i] = x; else PM2_G(Tp, gexpr)[i] = x; }
+    PM2_TABLE(cmask, u64, cols_l, cmask, ar.cmeta())
+    PM2_TABLE(wmask, u64, cols_l, wmask, ar.cmeta() + P)
+    PM2_TABLE(cbi, int, cols_l, cbi, (int *)(ar.cmeta() + 2 * (size_t)P))
+    PM2_TABLE(counts, int, idcap, counts, ar.counts())
+    PM2_TABLE(cn, int, idcap, cn, ar.cn())
+    PM2_TABLE(ncop, int, idcap, ncop, ar.ncop())
+    PM2_TABLE(firstp, int, idcap, firstp, ar.firstp())
+    PM2_TABLE(tgt, int, idcap, tgt, ar.tgt())
+#undef PM2_TABLE
+    PM2_DEV void cmask_or(int c, u64 bits) const { if (c < cols_l) pm2_atomic_or(lds<u64>(base + lay->cmask) + c, bits); else pm2_atomic_or(ar.cmeta() + c, bits); }
+    PM2_DEV void ncop_add(int id, int x) const { if (id < idcap) pm2_atomic_add(lds<int>(base + lay->ncop) + id, x); else pm2_atomic_add(ar.ncop() + id, x); }
+    PM2_DEV int firstp_min(int id, int x) const { if (id < idcap) return pm2_atomic_min(lds<int>(base + lay->firstp) + id, x); return pm2_atomic_min(ar.firstp() + id, x); }
     PM2_DEV int slot_of(int id) const { return id < idcap ? (int)lds<u8>(base + lay->slotmap)[id] : NONE8; }
     PM2_DEV void slot_set(int id, int s) const { if (id < idcap) lds<u8>(base + lay->slotmap)[id] = (u8)s; }
     PM2_DEV double *ta_row(int j) const { return j < NS ? lds<double>(base + lay->ta) + j * Dp : lds<double>(base + lay->tax) + (j - NS) * Dp; }
@@ -212,21 +242,85 @@ PM2_DEV double shfl_d(double v, int src)
     return b.d;
 }
 PM2_DEV int shfl_i(int v, int src) { return (int)(unsigned)PM2_SHFL64((u64)(unsigned)v, src); }
-// the value of lane `src` (wave-uniform): v_readlane on the device
+#ifdef PM2_EMU
+// the value of lane `src` (wave-uniform)
 PM2_DEV int readlane_i(int v, int src) { return shfl_i(v, src); }
-
+PM2_DEV u64 readlane_u64(u64 v, int src) { return PM2_SHFL64(v, src); }
 PM2_DEV double wave_max_d(double v)
 {
     const int lane = PM2_TID() & 63;
     for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = (t > v) ? t : v; }
     return v;
 }
+PM2_DEV double wave_min_d(double v)
+{
+    const int lane = PM2_TID() & 63;
+    for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = (t < v) ? t : v; }
+    return v;
+}
+// (the device's order: quad, quad pair, half row, row, then (r0 + r1) + (r2 + r3) over the four rows of sixteen lanes)
 PM2_DEV double wave_sum_d(double v)
 {
     const int lane = PM2_TID() & 63;
-    for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = v + t; }
-    return v;
+    v = v + shfl_d(v, lane ^ 1);
+    v = v + shfl_d(v, lane ^ 2);
+    v = v + shfl_d(v, (lane & ~7) | (7 - (lane & 7)));         // row_half_mirror
+    v = v + shfl_d(v, (lane & ~15) | (15 - (lane & 15)));      // row_mirror
+    return (shfl_d(v, 0) + shfl_d(v, 16)) + (shfl_d(v, 32) + shfl_d(v, 48));
 }
+#else
+// the value of lane `src` (wave-uniform): v_readlane, no LDS round trip
+PM2_DEV int readlane_i(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+PM2_DEV u64 readlane_u64(u64 v, int src)
+{
+    const int s_ = __builtin_amdgcn_readfirstlane(src);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, s_), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), s_);
+    return ((u64)hi << 32) | (u64)lo;
+}
+// wave-level reductions of a double on the DPP network: xor-1 and xor-2 inside quads, half-row and row mirrors give every lane its
+// 16-lane row total; the four row totals are read with v_readlane.  All 64 lanes must be active.
+template <int CTRL> PM2_DEV double dpp_d(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+PM2_DEV double readlane_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+PM2_DEV double wave_sum_d(double v)
+{
+    v += dpp_d<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);     // row_half_mirror
+    v += dpp_d<0x140>(v);     // row_mirror
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+PM2_DEV double wave_max_d(double v)
+{
+    double t;
+    t = dpp_d<0xB1>(v); v = (t > v) ? t : v;
+    t = dpp_d<0x4E>(v); v = (t > v) ? t : v;
+    t = dpp_d<0x141>(v); v = (t > v) ? t : v;
+    t = dpp_d<0x140>(v); v = (t > v) ? t : v;
+    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+    const double m01 = (r1 > r0) ? r1 : r0, m23 = (r3 > r2) ? r3 : r2;
+    return (m23 > m01) ? m23 : m01;
+}
+PM2_DEV double wave_min_d(double v)
+{
+    double t;
+    t = dpp_d<0xB1>(v); v = (t < v) ? t : v;
+    t = dpp_d<0x4E>(v); v = (t < v) ? t : v;
+    t = dpp_d<0x141>(v); v = (t < v) ? t : v;
+    t = dpp_d<0x140>(v); v = (t < v) ? t : v;
+    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+    const double m01 = (r1 < r0) ? r1 : r0, m23 = (r3 < r2) ? r3 : r2;
+    return (m23 < m01) ? m23 : m01;
+}
+#endif
 // exclusive prefix sum of an int over the wave, and the total
 PM2_DEV int wave_excl_scan_i(int v, int &total)
 {
@@ -245,17 +339,33 @@ PM2_DEV int popc_below64(const u64 *bm, int p)
     return n + pm2_popc64(bm[w] & ((1ull << (p & 63)) - 1ull));
 }
 
+// A small array that lives in registers: NN separate scalar fields (no array type, so nothing can ever turn an access into a
+// run-time-indexed memory access); a run-time index is a chain of selects, a compile-time one folds away.
+template <class Tp, int NN>
+struct RegArr {
+    Tp head;
+    RegArr<Tp, NN - 1> tail;
+    PM2_DEV Tp operator[](int i) const { return i == 0 ? head : tail[i - 1]; }
+    PM2_DEV void set(int i, Tp x) { head = (i == 0) ? x : head; tail.set(i - 1, x); }
+};
+template <class Tp>
+struct RegArr<Tp, 1> {
+    Tp head;
+    PM2_DEV Tp operator[](int) const { return head; }
+    PM2_DEV void set(int i, Tp x) { head = (i == 0) ? x : head; }
+};
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 template <int K, int PPL>
 struct Sweep2 {
     // ---- per-lane state ----
-    double lw[PPL];
+    RegArr<double, PPL> lw;
     static constexpr int NCP = (PPL + 1) / 2;
-    unsigned colp[K][NCP];      // column index of the lane's particles per dataset, 16 bits each
+    RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
     unsigned cslp;              // class slot of the lane's particles per dataset, 2 bits each: bit offset 2 * (k * PPL + u)
-    double c_mu[NS], c_lam[NS], c_sg[NS], c_bt[NS];     // owner wave: the cluster cache of its dataset, lane = feature
+    RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
     // ---- uniform ----
-    const SweepArgs *ap;
+    const PM2_CONST SweepArgs *ap;
     int tid, lane, wave, chain;
     int N, P;
     unsigned long long seed;
@@ -270,7 +380,7 @@ struct Sweep2 {
         for (int kk = 0; kk < K; ++kk)
             if (kk == k) {
 #pragma unroll
-                for (int u = 0; u < PPL; ++u) ck[u] = (int)((colp[kk][u >> 1] >> ((u & 1) * 16)) & 0xffffu);
+                for (int u = 0; u < PPL; ++u) ck[u] = (int)((colp[kk * NCP + (u >> 1)] >> ((u & 1) * 16)) & 0xffffu);
             }
     }
     PM2_DEV void col_put(int k, const int (&ck)[PPL])
@@ -284,8 +394,17 @@ struct Sweep2 {
         for (int kk = 0; kk < K; ++kk)
             if (kk == k) {
 #pragma unroll
-                for (int j = 0; j < NCP; ++j) colp[kk][j] = pk[j];
+                for (int j = 0; j < NCP; ++j) colp.set(kk * NCP + j, pk[j]);
             }
+    }
+    // lw[u] for a run-time u (registers: selects, never a run-time index)
+    PM2_DEV double lw_get(int u) const
+    {
+        return lw[u];
+    }
+    PM2_DEV void lw_set(int u, double x)
+    {
+        lw.set(u, x);
     }
     PM2_DEV int csl_get(int k, int u) const { return (int)((cslp >> (2 * (k * PPL + u))) & 3u); }
     PM2_DEV void csl_put(int k, int u, int r) { const int sh = 2 * (k * PPL + u); cslp = (cslp & ~(3u << sh)) | ((unsigned)r << sh); }
@@ -311,7 +430,7 @@ struct Sweep2 {
         pmdi_arith::gauss_ml(cnv, sg, bt, mu, lam);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-            if (s == s0) { c_sg[s] = sg; c_bt[s] = bt; c_mu[s] = mu; c_lam[s] = lam; }
+            if (s == s0) { c_mu.set(s, mu); c_lam.set(s, lam); }
         if (lane < v.D) v.ta_row(s0)[lane] = 0.5 * log(lam / ((double)cnv + 1.0));            // gaussian_cluster.jl:45
         if (lane == 0) {
             lds<int>(v.base + L.slot_cn)[s0] = cnv;
@@ -323,11 +442,11 @@ struct Sweep2 {
     PM2_DEV void prefix(int k)
     {
         const DV v = view(k);
-        const DsetDev &d = ap->ds[k];
+        const auto &d = ap->ds[k];
         const int D = d.D;
         int *dsc = v.dsc();
-        const int *s_in = PM2_G(const int, ap->s_in) + ((size_t)chain * K + k) * n;
-        const int *order = PM2_G(const int, ap->order) + (size_t)chain * n;
+        auto s_in = PM2_G(const int, ap->s_in) + ((size_t)chain * K + k) * n;
+        auto order = PM2_G(const int, ap->order) + (size_t)chain * n;
         const u8 *flags = ap->flags ? PM2_G(const u8, ap->flags) + (size_t)chain * ap->sumD + d.flag_off : (const u8 *)nullptr;
         u8 *fl = lds<u8>(L.xfl) + k * 64;
         int *lab = lds<int>(v.trb + L.tr_tb);               // [0,64) first position, [64,128) id, [128,192) count (the tb rows are idle)
@@ -342,11 +461,13 @@ struct Sweep2 {
         if (lane < 64) { lab[lane] = 0x7fffffff; lab[64 + lane] = 0; lab[128 + lane] = 0; fl[lane] = (lane < D) ? (flags ? flags[lane] : (u8)1) : (u8)0; }
         // what lives in the arena: new_id (:167), the per-id scratch beyond idcap, the column tables beyond cols_l
         {
-            int *nid = PM2_G(int, v.ar.newid());
+            auto nid = PM2_G(int, v.ar.newid());
             for (int e = lane; e < N * P; e += 64) nid[e] = 0;
-            int *g1 = PM2_G(int, v.ar.ncop()), *g2 = PM2_G(int, v.ar.firstp()), *g3 = PM2_G(int, v.ar.counts());
+            auto g1 = PM2_G(int, v.ar.ncop());
+            auto g2 = PM2_G(int, v.ar.firstp());
+            auto g3 = PM2_G(int, v.ar.counts());
             for (int e = v.idcap + lane; e <= ap->cap; e += 64) { g1[e] = 0; g2[e] = 0x7fffffff; g3[e] = 0; }
-            u64 *cm = PM2_G(u64, v.ar.cmeta());
+            auto cm = PM2_G(u64, v.ar.cmeta());
             for (int e = v.cols_l + lane; e < P; e += 64) { cm[e] = 0; cm[P + e] = 0; }
         }
         PM2_WAVE_BARRIER();
@@ -367,18 +488,18 @@ struct Sweep2 {
                 for (int u = 0; u < N; ++u) r += (lab[u] < fp) ? 1 : 0;
                 id = 2 + r;                                    // cluster id of label u (:197)
                 lab[64 + lane] = id;
-                *v.counts_p(id) = P;
-                *v.cn_p(id) = lab[128 + lane];
+                v.counts_set(id, P);
+                v.cn_set(id, lab[128 + lane]);
             }
             v.tab_set(0, lane, id);                            // particle[u, :, k] .= id (:195): one column
         }
-        if (lane == 0) { *v.counts_p(1) = P * N - nu * P; *v.cn_p(1) = 0; }
+        if (lane == 0) { v.counts_set(1, P * N - nu * P); v.cn_set(1, 0); }
         PM2_WAVE_BARRIER();
         // fresh clusters and the first n1-1 shuffled observations joining their previous cluster, sequentially in shuffled
         // order (:189,:194,:201-206): lane = feature, one label after the other
         {
-            double *sb = PM2_G(double, v.ar.sb());
-            const double *xf = PM2_G(const double, d.xf);
+            auto sb = PM2_G(double, v.ar.sb());
+            auto xf = PM2_G(const double, d.xf);
             if (lane < D) { sb[((size_t)1 * D + lane) * 2] = 0.0; sb[((size_t)1 * D + lane) * 2 + 1] = 0.5; }
             for (int u = 0; u < N; ++u) {
                 const int id = lab[64 + u];
@@ -400,6 +521,7 @@ struct Sweep2 {
             int nf = 0;
             for (int q = 0; q < D; ++q) nf += fl[q];
             dsc[DS_NFLAG] = nf; dsc[DS_MAXID] = nu + 1; dsc[DS_NCLS] = 1; dsc[DS_NCOL] = 1; dsc[DS_ND] = 0; dsc[DS_NK] = 0; dsc[DS_NX] = 0;
+            dsc[DS_DIRTY] = 1; dsc[DS_CHANGED] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_NEEDMASK] = 0; dsc[DS_NCLONE] = 0;
             lds<int>(v.base + L.clsval)[0] = 1; lds<int>(v.base + L.clslead)[0] = 0; lds<int>(v.base + L.leadcol)[0] = 0;
         }
         PM2_WAVE_BARRIER();
@@ -410,7 +532,7 @@ struct Sweep2 {
     PM2_DEV void phase_a(int k, double x, int i_obs, long long pos)
     {
         const DV v = view(k);
-        const DsetDev &d = ap->ds[k];
+        const auto &d = ap->ds[k];
         const int D = d.D;
         int *dsc = v.dsc();
         const int ncls = PM2_UNI(dsc[DS_NCLS]);
@@ -419,9 +541,16 @@ struct Sweep2 {
         u8 *itemj = lds<u8>(v.base + L.itemj);
         int *slot_id = lds<int>(v.base + L.slot_id);
         int *xid = lds<int>(v.base + L.xid);
-        // -- A1: the clusters the class leaders' columns hold; their cache slots (stable while a cluster stays reachable)
+        // -- A1: the clusters the class leaders' columns hold; their cache slots (stable while a cluster stays reachable).  Skipped
+        // while nothing it depends on has changed (phase C and the resampling say so): most steps of a settled chain
         unsigned needmask = 0;
         int nx = 0;
+#ifdef PM2_EMU
+        if (getenv("PM2_FORCE_DIRTY") && lane == 0) dsc[DS_DIRTY] = 1;
+        PM2_WAVE_BARRIER();
+#endif
+        if (PM2_UNI(dsc[DS_DIRTY]) == 0) { needmask = (unsigned)PM2_UNI(dsc[DS_NEEDMASK]); nx = PM2_UNI(dsc[DS_NX]); }
+        else {
         int item_id[CLS];
         int nid_pref[CLS];
 #pragma unroll
@@ -464,10 +593,10 @@ struct Sweep2 {
                             v.slot_set(id0, s0);
                         }
                         needmask |= 1u << s0;
-                        const double *sb = PM2_G(const double, v.ar.sb());
+                        auto sb = PM2_G(const double, v.ar.sb());
                         double sg = 0.0, bt = 0.5;
                         if (lane < D) { sg = sb[((size_t)id0 * D + lane) * 2]; bt = sb[((size_t)id0 * D + lane) * 2 + 1]; }
-                        cache_fill(v, k, s0, sg, bt, *v.cn_p(id0));
+                        cache_fill(v, k, s0, sg, bt, v.cn_get(id0));
                         row = s0;
                     } else {
                         if (nx >= XCAP) { if (lane == 0) sc()[SC_FAIL] = 2; nx = XCAP - 1; }          // too many uncached reachable clusters
@@ -489,15 +618,17 @@ struct Sweep2 {
             if (lane < NS && ((dead >> lane) & 1u)) { const int old = slot_id[lane]; if (old) { v.slot_set(old, NONE8); slot_id[lane] = 0; } }
         }
         const int nneed = __builtin_popcount(needmask) + nx;
-        if (lane == 0) { dsc[DS_NX] = nx; dsc[DS_NNEED] = nneed; }
+        if (lane == 0) { dsc[DS_NX] = nx; dsc[DS_NNEED] = nneed; dsc[DS_NEEDMASK] = (int)needmask; }
         PM2_WAVE_BARRIER();
+        }
         // -- A2: the per-feature terms: cached clusters need one log per feature (gaussian_cluster.jl:46-48), lane = feature
-#pragma unroll
+#pragma nounroll
         for (int s = 0; s < NS; ++s) {
             if ((needmask >> s) & 1u) {
+                const double mu = c_mu[s], lam = c_lam[s];
                 const double nd_ = (double)lds<int>(v.base + L.slot_cn)[s];
-                const double dd = x - c_mu[s];
-                const double tb = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * c_lam[s]);
+                const double dd = x - mu;
+                const double tb = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
                 if (lane < D) v.tb_row(s)[lane] = tb;
             }
         }
@@ -515,8 +646,8 @@ struct Sweep2 {
             PM2_WAVE_BARRIER();
             for (int e = e0; e < nx && e < e0 + XR; ++e) {
                 const int id = xid[e];
-                const int cnv = *v.cn_p(id);
-                const double *sb = PM2_G(const double, v.ar.sb());
+                const int cnv = v.cn_get(id);
+                auto sb = PM2_G(const double, v.ar.sb());
                 if (on) {
                     double mu, lam;
                     pmdi_arith::gauss_ml(cnv, sb[((size_t)id * D + lane) * 2], sb[((size_t)id * D + lane) * 2 + 1], mu, lam);
@@ -529,7 +660,7 @@ struct Sweep2 {
             if (lane < XR && e0 + lane < nx) {
                 const int id = xid[e0 + lane];
                 const double *ta = v.ta_row(NS + lane), *tb = v.tb_row(NS + lane);
-                double out = (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[*v.cn_p(id)];
+                double out = (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[v.cn_get(id)];
                 for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
                 lp[NS + e0 + lane] = out;
             }
@@ -538,7 +669,7 @@ struct Sweep2 {
         // -- A4: mutation CDF per particle class (:231-248): lanes = (class, label); max / cumsum / normalise through a per-wave
         // exchange area.  The cumsum follows Julia's accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]) (n < 128).
         {
-            const double *pik = PM2_G(const double, ap->Pi) + ((size_t)chain * K + k) * N;
+            auto pik = PM2_G(const double, ap->Pi) + ((size_t)chain * K + k) * N;
             double *wv = lds<double>(v.trb + L.tr_tb);          // (the tb rows are dead: the sums are done)
             const int G = 64 / N;
             const int g = lane / N, nn = lane - g * N;
@@ -607,7 +738,7 @@ struct Sweep2 {
     PM2_DEV bool phase_c(int k, double x, long long pos)
     {
         const DV v = view(k);
-        const DsetDev &d = ap->ds[k];
+        const auto &d = ap->ds[k];
         const int D = d.D;
         int *dsc = v.dsc();
         const u8 *fl = flk(k);
@@ -618,12 +749,19 @@ struct Sweep2 {
         unsigned *minp = lds<unsigned>(v.base + L.minp);
         u64 *bmc = lds<u64>(v.base + L.bmc), *bmf = lds<u64>(v.base + L.bmf);
         if (nd > NDCAP) { if (lane == 0) sc()[SC_FAIL] = 3; return false; }          // too many distinct chosen clusters
+        // the statistics of the first chosen cluster (the only one in most steps), on their way while the bookkeeping runs
+        double pf_sg = 0.0, pf_bt = 0.5;
+        if (nd > 0 && lane < D) {
+            auto sb0 = PM2_G(const double, v.ar.sb());
+            const int c0 = clist[0];
+            pf_sg = sb0[((size_t)c0 * D + lane) * 2]; pf_bt = sb0[((size_t)c0 * D + lane) * 2 + 1];
+        }
         // -- C1: clone or in place (:286-299): a chosen cluster all of whose references were chosen is updated in place
         for (int e0 = 0; e0 < nd; e0 += 64) {
             const int e = e0 + lane;
             if (e < nd) {
                 const int c = clist[e];
-                if (*v.ncop_p(c) != *v.counts_p(c)) { const int fp = *v.firstp_p(c); pm2_atomic_or(&bmc[fp >> 6], 1ull << (fp & 63)); }
+                if (v.ncop_get(c) != v.counts_get(c)) { const int fp = v.firstp_get(c); pm2_atomic_or(&bmc[fp >> 6], 1ull << (fp & 63)); }
             }
         }
         PM2_WAVE_BARRIER();
@@ -634,13 +772,14 @@ struct Sweep2 {
             const int e = e0 + lane;
             if (e < nd) {
                 const int c = clist[e];
-                const int ncp = *v.ncop_p(c), fp = *v.firstp_p(c);
-                const bool needs = ncp != *v.counts_p(c);
+                const int ncp = v.ncop_get(c), fp = v.firstp_get(c);
+                const int cnt_c = v.counts_get(c);
+                const bool needs = ncp != cnt_c;
                 const int t = needs ? maxid + 1 + popc_below64(bmc, fp) : c;       // first-appearance order over the particles (:290-292)
-                *v.tgt_p(c) = t;
-                const int nnew = *v.cn_p(c) + 1;
-                if (needs) { *v.counts_p(c) -= ncp; *v.counts_p(t) = ncp; }         // (:293-294)
-                *v.cn_p(t) = nnew;
+                v.tgt_set(c, t);
+                const int nnew = v.cn_get(c) + 1;
+                if (needs) { v.counts_set(c, cnt_c - ncp); v.counts_set(t, ncp); }         // (:293-294)
+                v.cn_set(t, nnew);
             }
         }
         // -- C2: class ids of the next step (:266-272): a (class, label) key met for the first time in this Gibbs iteration gets
@@ -663,7 +802,9 @@ struct Sweep2 {
                 if (v0 <= 0) {
                     v0 = 1 + popc_below64(bmf, (int)(minp[key] >> 16));            // curr_id += 1 (:267-269)
                     if (ap->q1 == 0) PM2_G(int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + ns] = v0;
+                    dsc[DS_CHANGED] = 1;                                            // (new_id changed under a key of this class)
                 }
+                if (v0 != lds<int>(v.base + L.clsval)[r]) dsc[DS_CHANGED] = 1;       // (the class does not map to itself)
                 kval[j] = v0;
             }
         }
@@ -687,18 +828,21 @@ struct Sweep2 {
         // -- C3: column splits (:301-308): particles of one column that chose the same label move together; the group whose chosen
         // cluster was cloned takes a copy of the column with that entry replaced -- or the column itself when nobody stays behind
         int ncol_new = ncol;
+        if (nclone == 0) {                                   // nothing was cloned: no column changes, only the chosen-label masks go back to idle
+            for (int cc = lane; cc < ncol; cc += 64) v.cmask_set(cc, 0);
+        } else
         for (int c0 = 0; c0 < ncol; c0 += 64) {
             const int cc = c0 + lane;
             u64 wm = 0;
             bool keeper = false;
             if (cc < ncol) {
-                u64 cm = *v.cmask_p(cc);
-                *v.cmask_p(cc) = 0;
+                u64 cm = v.cmask_get(cc);
+                v.cmask_set(cc, 0);
                 while (cm) {
                     const int ns = pm2_ffs64(cm) - 1;
                     cm &= cm - 1;
                     const int c = v.tab_get(cc, ns);
-                    if (*v.tgt_p(c) != c) wm |= 1ull << ns; else keeper = true;
+                    if (v.tgt_get(c) != c) wm |= 1ull << ns; else keeper = true;
                 }
             }
             const int nw = pm2_popc64(wm);
@@ -706,16 +850,14 @@ struct Sweep2 {
             const int inpl = (!keeper && nw > 0) ? pm2_ffs64(wm) - 1 : -1;
             int tot;
             const int base = ncol_new + wave_excl_scan_i(nnew, tot);
-            if (cc < ncol) { *v.wmask_p(cc) = wm; *v.cbi_p(cc) = (base << 8) | (inpl + 1); }
+            if (cc < ncol) { v.wmask_set(cc, wm); v.cbi_set(cc, (base << 8) | (inpl + 1)); }
             // the copies, then the in-place entry (the copies read the column as it was)
             u64 m;
             bool todo = wm != 0;
             while ((m = PM2_BALLOT(todo)) != 0) {
                 const int l0 = pm2_ffs64(m) - 1;
                 const int cs = c0 + l0;
-                union { u64 u; double dd; } uw; uw.u = wm;
-                union { u64 u; double dd; } ur; ur.dd = shfl_d(uw.dd, l0);
-                u64 wm0 = ur.u;
+                u64 wm0 = readlane_u64(wm, l0);
                 const int base0 = readlane_i(base, l0), inpl0 = readlane_i(inpl, l0);
                 int rnk = 0;
                 while (wm0) {
@@ -723,13 +865,13 @@ struct Sweep2 {
                     wm0 &= wm0 - 1;
                     if (ns != inpl0) {
                         const int newc = base0 + rnk - (inpl0 >= 0 ? 1 : 0);
-                        const int t = *v.tgt_p(v.tab_get(cs, ns));
+                        const int t = v.tgt_get(v.tab_get(cs, ns));
                         if (lane < N) v.tab_set(newc, lane, lane == ns ? t : v.tab_get(cs, lane));
                     }
                     rnk += 1;
                 }
                 PM2_WAVE_BARRIER();                            // (the copies have read the column as it was)
-                if (inpl0 >= 0 && lane == 0) v.tab_set(cs, inpl0, *v.tgt_p(v.tab_get(cs, inpl0)));
+                if (inpl0 >= 0 && lane == 0) v.tab_set(cs, inpl0, v.tgt_get(v.tab_get(cs, inpl0)));
                 if (lane == l0) todo = false;
             }
             ncol_new += tot;
@@ -750,10 +892,10 @@ struct Sweep2 {
                 if (krep[j]) {
                     const int pl = (int)(mpr >> 16), cl = (int)(mpr & 0xffffu);
                     const int ns = key - (key / N) * N;
-                    const u64 wm = *v.wmask_p(cl);
+                    const u64 wm = nclone ? v.wmask_get(cl) : 0ull;          // (without a clone the column tables were not written)
                     int newc = cl;
                     if ((wm >> ns) & 1ull) {
-                        const int bi = *v.cbi_p(cl);
+                        const int bi = v.cbi_get(cl);
                         const int inpl = (bi & 0xff) - 1, base = bi >> 8;
                         const int rnk = pm2_popc64(wm & ((1ull << ns) - 1ull));
                         newc = (inpl >= 0) ? (ns == inpl ? cl : base + rnk - 1) : base + rnk;
@@ -771,22 +913,18 @@ struct Sweep2 {
             fprintf(stderr, "\n");
         }
 #endif
-        // -- C4: deepcopy + cluster_add! of every distinct chosen cluster (:297,:300), lane = feature; a cached cluster is updated in
-        // its registers (and written through to the pool), the others go through the pool
+        // -- C4: deepcopy + cluster_add! of every distinct chosen cluster (:297,:300), lane = feature: (Sigma, beta) from the pool (the
+        // first cluster's were fetched at the top of the phase), written to the pool; a cached cluster gets its mu, lambda and first
+        // term refreshed in the owner wave's registers
         {
-            double *sb = PM2_G(double, v.ar.sb());
+            auto sb = PM2_G(double, v.ar.sb());
             for (int e = 0; e < nd; ++e) {
                 const int c = clist[e];
-                const int t = *v.tgt_p(c);
-                const int nnew = *v.cn_p(t);
+                const int t = v.tgt_get(c);
+                const int nnew = v.cn_get(t);
                 const int s0 = v.slot_of(c);
-                double sg = 0.0, bt = 0.5;
-                if (s0 != NONE8) {
-#pragma unroll
-                    for (int s = 0; s < NS; ++s) if (s == s0) { sg = c_sg[s]; bt = c_bt[s]; }
-                } else if (lane < D) {
-                    sg = sb[((size_t)c * D + lane) * 2]; bt = sb[((size_t)c * D + lane) * 2 + 1];
-                }
+                double sg = pf_sg, bt = pf_bt;
+                if (e > 0 && lane < D) { sg = sb[((size_t)c * D + lane) * 2]; bt = sb[((size_t)c * D + lane) * 2 + 1]; }
                 const bool on = lane < D && fl[lane];
                 if (on) pmdi_arith::gauss_add_sb(x, nnew, sg, bt);
                 if (lane < D && (on || t != c)) { sb[((size_t)t * D + lane) * 2] = sg; sb[((size_t)t * D + lane) * 2 + 1] = bt; }
@@ -797,7 +935,7 @@ struct Sweep2 {
         PM2_WAVE_BARRIER();
         for (int e0 = 0; e0 < nd; e0 += 64) {
             const int e = e0 + lane;
-            if (e < nd) { const int c = clist[e]; *v.ncop_p(c) = 0; *v.firstp_p(c) = 0x7fffffff; }
+            if (e < nd) { const int c = clist[e]; v.ncop_set(c, 0); v.firstp_set(c, 0x7fffffff); }
         }
         for (int j0 = 0; j0 < nk; j0 += 64) { const int j = j0 + lane; if (j < nk) minp[klist[j]] = INFU; }
         for (int w = lane; w < P / 64 + 1; w += 64) { bmc[w] = 0; bmf[w] = 0; }
@@ -812,6 +950,13 @@ struct Sweep2 {
             long long *w_ = wk(k);
             w_[WK_EVAL] += dsc[DS_NNEED]; w_[WK_UPD] += nd; w_[WK_CLONE] += nclone; w_[WK_SPLITS] += ncol_new - ncol;
             dsc[DS_MAXID] = maxid + nclone; dsc[DS_NCLS] = nrep; dsc[DS_NCOL] = ncol_new; dsc[DS_ND] = 0; dsc[DS_NK] = 0; dsc[DS_NCLONE] = nclone;
+            // the particles have something to follow when a column was split or written, or when the class slots move: not when the
+            // step had one class, one (class, label) key and no clone (the key's class is slot 0 again)
+            dsc[DS_FOLLOW] = (nclone != 0 || ncls != 1 || nk != 1) ? 1 : 0;
+            // ... and the next step of this dataset reads the same clusters through the same class, under unchanged new_id entries,
+            // when on top of that the one key was known and kept its class value: the need set of phase A stands as it is
+            dsc[DS_DIRTY] = (nclone != 0 || ncls != 1 || nk != 1 || dsc[DS_CHANGED] != 0) ? 1 : 0;
+            dsc[DS_CHANGED] = 0;
         }
         (void)pos;
         return true;
@@ -830,15 +975,15 @@ struct Sweep2 {
             if (lane == l0) {
                 const int cnt = pm2_popc64(m);
                 // chosen cluster: copies and first particle (:279)
-                const int old = pm2_atomic_add(v.ncop_p(c), cnt);
-                pm2_atomic_min(v.firstp_p(c), p);
-                if (old == 0) { const int idx = pm2_atomic_add(&dsc[DS_ND], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[idx] = (u16)c; }
+                const int old = v.firstp_min(c, p);          // (idle value INF: the first toucher of a cluster sees it and lists the cluster)
+                v.ncop_add(c, cnt);
+                if (old == 0x7fffffff) { const int idx = pm2_atomic_add(&dsc[DS_ND], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[idx] = (u16)c; }
                 // (class, label) key: first particle, with its column
                 const int key = r * N + ns;
                 const unsigned oldk = pm2_atomic_min(&lds<unsigned>(v.base + L.minp)[key], ((unsigned)p << 16) | (unsigned)cl);
                 if (oldk == INFU) { const int idx = pm2_atomic_add(&dsc[DS_NK], 1); lds<int>(v.base + L.klist)[idx] = key; }
                 // labels chosen on this column
-                pm2_atomic_or(v.cmask_p(cl), 1ull << ns);
+                v.cmask_or(cl, 1ull << ns);
             }
             rem &= ~m;
         }
@@ -987,7 +1132,7 @@ struct Sweep2 {
         for (int uu = 0; uu < PPL; ++uu) {
             const int p = tid * PPL + uu;
             anc[p] = (p == 0) ? (u16)0 : (p <= js ? raw[p - 1] : raw[p]);
-            lw[uu] = 1.0;                                     // src/pmdi.jl:319
+            lw.set(uu, 1.0);                                  // src/pmdi.jl:319
         }
         PM2_BARRIER();
         // per dataset (:320-340); the u table is dead: its LDS holds the gather tables
@@ -1076,7 +1221,7 @@ struct Sweep2 {
                 PM2_BARRIER();
                 int basew = newmax, tot = 0;
                 for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[48 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
-                if (id <= oldmax) *v.tgt_p(id) = live ? basew + pm2_popc64(bal & ((1ull << lane) - 1ull)) + 1 : 0;
+                if (id <= oldmax) v.tgt_set(id, live ? basew + pm2_popc64(bal & ((1ull << lane) - 1ull)) + 1 : 0);
                 newmax += tot;
                 PM2_BARRIER();
             }
@@ -1086,9 +1231,9 @@ struct Sweep2 {
                 const int id = 1 + b + tid;
                 int nid = 0, occ = 0, cnv = 0;
                 if (id <= oldmax) {
-                    nid = *v.tgt_p(id);
+                    nid = v.tgt_get(id);
                     occ = (id < v.idcap) ? hist[id] : PM2_G(int, v.ar.ncop())[id];
-                    cnv = *v.cn_p(id);
+                    cnv = v.cn_get(id);
                     if (id >= v.idcap) PM2_G(int, v.ar.ncop())[id] = 0;
                 }
                 {
@@ -1097,20 +1242,20 @@ struct Sweep2 {
                 }
                 PM2_BARRIER();
                 if (id <= oldmax) {
-                    if (nid) { *v.counts_p(nid) = occ; *v.cn_p(nid) = cnv; }
-                    if (id > newmax) *v.counts_p(id) = 0;
+                    if (nid) { v.counts_set(nid, occ); v.cn_set(nid, cnv); }
+                    if (id > newmax) v.counts_set(id, 0);
                 }
                 PM2_BARRIER();
             }
             // ... and the statistics: clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending batches (:336)
             {
                 const int D = ap->ds[k].D;
-                double *sb = PM2_G(double, v.ar.sb());
+                auto sb = PM2_G(double, v.ar.sb());
                 const long long nitems = (long long)oldmax * D;
                 for (long long b = 0; b < nitems; b += T) {
                     const long long it = b + tid;
                     const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
-                    const int nid = (it < nitems) ? *v.tgt_p(id) : 0;
+                    const int nid = (it < nitems) ? v.tgt_get(id) : 0;
                     const bool mv = nid != 0 && nid != id;
                     double sg = 0.0, bt = 0.0;
                     if (mv) { sg = sb[((size_t)id * D + q) * 2]; bt = sb[((size_t)id * D + q) * 2 + 1]; }
@@ -1123,7 +1268,7 @@ struct Sweep2 {
             if (wave == k) {
                 int *slot_id = lds<int>(v.base + L.slot_id);
                 int olds = 0, news = 0;
-                if (lane < NS) { olds = slot_id[lane]; news = olds ? *v.tgt_p(olds) : 0; }
+                if (lane < NS) { olds = slot_id[lane]; news = olds ? v.tgt_get(olds) : 0; }
                 PM2_WAVE_BARRIER();
                 if (lane < NS && olds) v.slot_set(olds, NONE8);
                 PM2_WAVE_BARRIER();
@@ -1140,7 +1285,7 @@ struct Sweep2 {
                         const int idx = h * T + tid;
                         const int cc = c0 + idx / N, nn = idx - (idx / N) * N;
                         nv[h] = 0; dc[h] = -1; dn[h] = nn;
-                        if (idx < cpr * N && cc < ncol_old && mult[cc] != 0) { nv[h] = *v.tgt_p(v.tab_get(cc, nn)); dc[h] = cmap[cc]; }
+                        if (idx < cpr * N && cc < ncol_old && mult[cc] != 0) { nv[h] = v.tgt_get(v.tab_get(cc, nn)); dc[h] = cmap[cc]; }
                     }
                     PM2_BARRIER();
 #pragma unroll
@@ -1186,7 +1331,7 @@ struct Sweep2 {
                 for (int uu = 0; uu < PPL; ++uu) csl_put(k, uu, rk[uu]);
                 if (tid == 0) {
                     const int moved = sc()[SC_TMP0];
-                    dsc[DS_NCLS] = nc2; dsc[DS_NCOL] = ncol_new; dsc[DS_MAXID] = newmax;
+                    dsc[DS_NCLS] = nc2; dsc[DS_NCOL] = ncol_new; dsc[DS_MAXID] = newmax; dsc[DS_DIRTY] = 1;
                     long long *w_ = wk(k);
                     w_[WK_COLS] += ncol_old; w_[WK_MOVED] += moved; w_[WK_MOVE_EVENTS] += moved ? 1 : 0;
                 }
@@ -1198,18 +1343,26 @@ struct Sweep2 {
     // ---- the whole sweep -----------------------------------------------------------------------------------------------------------
     PM2_DEV void run(const SweepArgs *ap_, int chain_)
     {
-        ap = ap_; chain = chain_;
-        const SweepArgs &a = *ap;
+        ap = (const PM2_CONST SweepArgs *)ap_; chain = chain_;
+        const auto &a = *ap;
         tid = PM2_TID(); lane = tid & 63; wave = tid >> 6;
         N = a.N; P = a.P; n = a.n; n1 = a.n1; iter = a.iter;
         seed = a.seed + (unsigned long long)chain;
         const long long t_start = PM2_CLOCK();
         const bool owner = wave < K;
-        const int *order = PM2_G(const int, a.order) + (size_t)chain * n;
-        const double *logphi = PM2_G(const double, a.logphi) + (size_t)chain * a.npairs;
+        auto order = PM2_G(const int, a.order) + (size_t)chain * n;
+        auto logphi = PM2_G(const double, a.logphi) + (size_t)chain * a.npairs;
         if (tid < SC_COUNT) sc()[tid] = 0;
         if (tid < 8) stat()[tid] = 0;
         if (tid < KMAX2 * 8) lds<long long>(L.wk)[tid] = 0;
+        if (tid < 16) lds<long long>(L.ph)[tid] = 0;
+        // phase timers (PMDI_PHASE_TIMERS): shader-clock totals of lane 0 -- [0] prefix, [1] cluster phase (its own dataset), [2] wait
+        // for the other owner waves, [3] particle phase, [4] wait, [5] ESS half + bookkeeping phase, [6] wait, [7] follow-up + ESS
+        // decision, [8] resampling, [9] finish, [14] whole sweep
+        long long ph_last = 0;
+        int ph_cur = 0;
+#define PH2(i_) do { if (a.phase && tid == 0) { const long long t_ = PM2_CLOCK(); lds<long long>(L.ph)[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_); } } while (0)
+        if (a.phase && tid == 0) ph_last = PM2_CLOCK();
         PM2_BARRIER();
         if (tid == 0) {
             // leaf decomposition of Julia's accumulate_pairwise! over [1, P) and its recursion as a post-order program
@@ -1228,17 +1381,18 @@ struct Sweep2 {
             sc()[SC_NLEAF] = nl; sc()[SC_NPROG] = np;
         }
 #pragma unroll
-        for (int u = 0; u < PPL; ++u) lw[u] = a.lw_init;
+        for (int u = 0; u < PPL; ++u) lw.set(u, a.lw_init);
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int j = 0; j < NCP; ++j) colp[k][j] = 0;
+            for (int j = 0; j < NCP; ++j) colp.set(k * NCP + j, 0u);
         cslp = 0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { c_mu[s] = 0.0; c_lam[s] = 1.0; c_sg[s] = 0.0; c_bt[s] = 0.5; }
+        for (int s = 0; s < NS; ++s) { c_mu.set(s, 0.0); c_lam.set(s, 1.0); }
         PM2_BARRIER();
         if (owner) prefix(wave);
         PM2_BARRIER();
+        PH2(1);
 
         // the observation row of the owner wave's dataset, one step ahead (lane = feature)
         double xnext = 0.0;
@@ -1246,6 +1400,8 @@ struct Sweep2 {
         if (owner && lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
         int failed = 0;
         for (long long pos = n1 - 1; pos < n; ++pos) {
+            PM2_LAUNDER(ap, SweepArgs);
+            PM2_FRESH_VGPR(tid); PM2_FRESH_VGPR(lane);
             const int i = i_next;
             const double x = xnext;
             if (pos + 1 < n) {
@@ -1253,10 +1409,14 @@ struct Sweep2 {
                 if (owner && lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
             }
             // ---- cluster phase: the K datasets side by side, one owner wave each
+            PH2(1);
             if (owner) phase_a(wave, x, i, pos);
+            PH2(2);
             PM2_BARRIER();
+            PH2(3);
             if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
-            // ---- particle phase (all lanes, all datasets): allocation draw (:251-265), census, weights (:227,:245), Phi (:312-314)
+            // ---- particle phase (all lanes, all datasets): allocation draw (:251-265), census, weights (:227,:245), Phi (:312-314).
+            // (Neither the datasets nor the lane's particles are unrolled: the step has to stay inside the instruction cache.)
             unsigned nsp[PPL];                                                  // the labels a particle drew, a byte per dataset
 #pragma unroll
             for (int u = 0; u < PPL; ++u) nsp[u] = 0;
@@ -1264,13 +1424,18 @@ struct Sweep2 {
             for (int k = 0; k < K; ++k) {
                 const DV v = view(k);
                 const int ns0 = v.dsc()[DS_NS0];
-                int ck[PPL];
-                col_get(k, ck);
-                unsigned packed = 0;
+                unsigned pk[NCP];
 #pragma unroll
+                for (int j2 = 0; j2 < NCP; ++j2) pk[j2] = colp[k * NCP + j2];
+                unsigned packed = 0;
+#pragma nounroll
                 for (int u = 0; u < PPL; ++u) {
                     const int p = tid * PPL + u;
                     const int r = csl_get(k, u);
+                    unsigned pw = pk[0];
+#pragma unroll
+                    for (int j2 = 1; j2 < NCP; ++j2) pw = ((u >> 1) == j2) ? pk[j2] : pw;
+                    const int cl = (int)((pw >> ((u & 1) * 16)) & 0xffffu);
                     const double *row = v.cdf_row(r);
                     const int hot = (int)row[N + 1];
                     int ns = 0;
@@ -1281,9 +1446,10 @@ struct Sweep2 {
                         // first label whose CDF exceeds u (:252-260) = the number of leading entries that do not exceed it
                         for (int t = 0; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
                     }
-                    lw[u] = lw[u] + row[N];                                     // logweight[p] += increment (:227,:245), dataset order
-                    const int c = v.tab_get(ck[u], ns);                         // sstar_id (:264)
-                    nsp[u] |= (unsigned)ns << (8 * k);
+                    lw_set(u, lw_get(u) + row[N]);                              // logweight[p] += increment (:227,:245), dataset order
+                    const int c = v.tab_get(cl, ns);                            // sstar_id (:264)
+#pragma unroll
+                    for (int j2 = 0; j2 < PPL; ++j2) nsp[j2] |= (u == j2) ? ((unsigned)ns << (8 * k)) : 0u;
                     packed |= (unsigned)ns << (8 * (u & 3));
                     if ((u & 3) == 3 || u == PPL - 1) {                         // sstar[p, i, k] (:265), four particles per store
                         u8 *ss = v.ar.sstar() + (size_t)pos * P + (size_t)tid * PPL + (u & ~3);
@@ -1292,7 +1458,7 @@ struct Sweep2 {
                         else *PM2_G(u8, ss) = (u8)packed;
                         packed = 0;
                     }
-                    census(v, r, ck[u], ns, c, p);
+                    census(v, r, cl, ns, c, p);
                 }
             }
             if (K > 1) {                                                        // Phi_upweight! (src/misc.jl:50-59)
@@ -1307,43 +1473,51 @@ struct Sweep2 {
                             wv_ += (((nsp[u] >> (8 * k1)) & 0xffu) == ((nsp[u] >> (8 * k2)) & 0xffu)) ? logphi[pr] : 0.0;
                             ++pr;
                         }
-                    lw[u] = wv_;
+                    lw.set(u, wv_);
                 }
             }
             double *red = lds<double>(L.red);
             {
-                double mx = lw[0];
+                double mx = lw[0], mn = lw[0];
 #pragma unroll
-                for (int u = 1; u < PPL; ++u) mx = (lw[u] > mx) ? lw[u] : mx;
-                mx = wave_max_d(mx);
-                if (lane == 0) red[wave] = mx;
+                for (int u = 1; u < PPL; ++u) { mx = (lw[u] > mx) ? lw[u] : mx; mn = (lw[u] < mn) ? lw[u] : mn; }
+                mx = wave_max_d(mx); mn = wave_min_d(mn);
+                if (lane == 0) { red[wave] = mx; red[4 + wave] = mn; }
             }
+            PH2(4);
             PM2_BARRIER();
-            // ---- calc_ESS (src/misc.jl:15-25), first half; the bookkeeping phase of the owner waves
-            double mx = red[0];
-            for (int w_ = 1; w_ < T / 64; ++w_) mx = (red[w_] > mx) ? red[w_] : mx;
-            {
+            PH2(5);
+            // ---- calc_ESS (src/misc.jl:15-25), first half; the bookkeeping phase of the owner waves.  If every log-weight is the
+            // same number the sums are exact (P ones): ESS == P, no exps
+            double mx = red[0], mn = red[4];
+            for (int w_ = 1; w_ < T / 64; ++w_) { mx = (red[w_] > mx) ? red[w_] : mx; mn = (red[4 + w_] < mn) ? red[4 + w_] : mn; }
+            const bool lw_flat = mx == mn;
+            if (!lw_flat) {
                 double sa = 0.0, sq = 0.0;
-#pragma unroll
-                for (int u = 0; u < PPL; ++u) { const double w = exp(lw[u] - mx); sa += w; sq += w * w; }
+#pragma nounroll
+                for (int u = 0; u < PPL; ++u) { const double w = exp(lw_get(u) - mx); sa += w; sq += w * w; }
                 sa = wave_sum_d(sa); sq = wave_sum_d(sq);
                 if (lane == 0) { red[8 + wave] = sa; red[12 + wave] = sq; }
             }
             if (owner) phase_c(wave, x, pos);
+            PH2(6);
             PM2_BARRIER();
+            PH2(7);
             if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
             // ---- every particle follows its group: new column, new class slot
 #pragma nounroll
             for (int k = 0; k < K; ++k) {
                 const DV v = view(k);
+                if (!v.dsc()[DS_FOLLOW]) continue;                              // nothing was cloned, the classes stand as they are
+                const bool cloned = v.dsc()[DS_NCLONE] != 0;
                 int ck[PPL];
                 col_get(k, ck);
 #pragma unroll
                 for (int u = 0; u < PPL; ++u) {
                     const int cl = ck[u], ns = (int)((nsp[u] >> (8 * k)) & 0xffu);
-                    const u64 wm = *v.wmask_p(cl);
+                    const u64 wm = cloned ? v.wmask_get(cl) : 0ull;
                     if ((wm >> ns) & 1ull) {
-                        const int bi = *v.cbi_p(cl);
+                        const int bi = v.cbi_get(cl);
                         const int inpl = (bi & 0xff) - 1, base = bi >> 8;
                         const int rnk = pm2_popc64(wm & ((1ull << ns) - 1ull));
                         ck[u] = (inpl >= 0) ? (ns == inpl ? cl : base + rnk - 1) : base + rnk;
@@ -1352,9 +1526,12 @@ struct Sweep2 {
                 }
                 col_put(k, ck);
             }
-            double sa = 0.0, sq = 0.0;
-            for (int w_ = 0; w_ < T / 64; ++w_) { sa += red[8 + w_]; sq += red[12 + w_]; }
-            double ess = (sa * sa) / sq;
+            double ess = (double)P;
+            if (!lw_flat) {
+                double sa = 0.0, sq = 0.0;
+                for (int w_ = 0; w_ < T / 64; ++w_) { sa += red[8 + w_]; sq += red[12 + w_]; }
+                ess = (sa * sa) / sq;
+            }
             // The tree-ordered sums agree with calc_ESS's sequential loop to ~1e-13 relative; the decision is a comparison, so when
             // ESS lands that close to P/2 (k equal weights and the rest negligible give exactly k in the reference's order, and
             // k = P/2 does happen) the sums are redone in the reference's order by one lane.
@@ -1375,11 +1552,13 @@ struct Sweep2 {
             }
             const bool res = ess <= 0.5 * (double)P;              // src/pmdi.jl:317
             if (res) {
+                PH2(8);
                 if (tid == 0) stat()[1] += 1;
                 resample(pos, mx);
+                PH2(7);
             }
             if (a.trace_on && tid == 0) {
-                double *tr = PM2_G(double, a.trace) + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
+                auto tr = PM2_G(double, a.trace) + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * K);
                 tr[0] = ess; tr[1] = res ? 1.0 : 0.0;
                 for (int k = 0; k < K; ++k) { tr[2 + k] = (double)view(k).dsc()[DS_MAXID]; tr[2 + K + k] = (double)view(k).dsc()[DS_NCLS]; }
             }
@@ -1396,22 +1575,29 @@ struct Sweep2 {
                 PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
             }
             if (failed == 1) {
-                const int *s_in = PM2_G(const int, a.s_in) + (size_t)chain * K * n;
-                int *s_out = PM2_G(int, a.s_out) + (size_t)chain * K * n;
+                auto s_in = PM2_G(const int, a.s_in) + (size_t)chain * K * n;
+                auto s_out = PM2_G(int, a.s_out) + (size_t)chain * K * n;
                 for (long long e = tid; e < (long long)K * n; e += T) s_out[e] = s_in[e];
             }
             return;
         }
+        PH2(9);
         finish(t_start);
+        PH2(10);
+        if (a.phase && tid == 0) {
+            lds<long long>(L.ph)[14] = PM2_CLOCK() - t_start;
+            for (int e = 0; e < 16; ++e) PM2_G(long long, a.phase)[(size_t)chain * 16 + e] = lds<long long>(L.ph)[e];
+        }
+#undef PH2
     }
 
     // ---- particle pick (src/pmdi.jl:345-350), s = sstar[p_star, :, :] (:373), counters, the state the debug export reads --------------
     PM2_DEV void finish(long long t_start)
     {
-        const SweepArgs &a = *ap;
+        const auto &a = *ap;
         double *red = lds<double>(L.red);
         double *wt = lds<double>(L.tr);
-        const int *order = PM2_G(const int, a.order) + (size_t)chain * n;
+        auto order = PM2_G(const int, a.order) + (size_t)chain * n;
         PM2_BARRIER();
         {
             double mx = lw[0];
@@ -1454,14 +1640,16 @@ struct Sweep2 {
         for (int k = 0; k < K; ++k) {
             const DV v = view(k);
             const int ncol = v.dsc()[DS_NCOL], maxid = v.dsc()[DS_MAXID];
-            int *tg = PM2_G(int, v.ar.tabg());
+            auto tg = PM2_G(int, v.ar.tabg());
             for (int e = tid; e < ncol * N && e < v.cols_l * N; e += T) tg[e] = (int)lds<u16>(v.base + L.tab)[e];
-            int *cg = PM2_G(int, v.ar.colg()), *pg = PM2_G(int, v.ar.pidg());
+            auto cg = PM2_G(int, v.ar.colg());
+            auto pg = PM2_G(int, v.ar.pidg());
             int ck[PPL];
             col_get(k, ck);
 #pragma unroll
             for (int u = 0; u < PPL; ++u) { cg[tid * PPL + u] = ck[u]; pg[tid * PPL + u] = lds<int>(v.base + L.clsval)[csl_get(k, u)]; }
-            int *cng = PM2_G(int, v.ar.cn()), *ctg = PM2_G(int, v.ar.counts());
+            auto cng = PM2_G(int, v.ar.cn());
+            auto ctg = PM2_G(int, v.ar.counts());
             for (int id = tid; id < v.idcap && id <= a.cap; id += T) { cng[id] = (id <= maxid) ? lds<int>(v.base + L.cn)[id] : cng[id]; ctg[id] = (id <= maxid) ? lds<int>(v.base + L.counts)[id] : 0; }
             for (int id = maxid + 1 + tid; id <= a.cap; id += T) ctg[id] = 0;
             if (tid == 0) {
@@ -1470,7 +1658,7 @@ struct Sweep2 {
             }
         }
         if (tid == 0) {
-            long long *st = PM2_G(long long, a.stats) + (size_t)chain * 8;
+            auto st = PM2_G(long long, a.stats) + (size_t)chain * 8;
             const long long *s = stat();
             PM2_G(int, a.pstar)[chain] = pstar;
             st[ST_NOPS] = s[0]; st[ST_NRESAMPLE] = s[1]; st[ST_NCLONES] = s[2]; st[ST_MAXID] = s[3]; st[ST_SUMCLASSES] = s[4];
