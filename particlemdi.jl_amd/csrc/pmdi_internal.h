@@ -79,7 +79,7 @@ struct S2Layout {
     int ds0, ds_stride;                               // dataset blocks
     // offsets inside a dataset block
     int tab, cmask, wmask, cbi, counts, cn, ncop, firstp, tgt, slotmap, ta, tax, lp, slot_id, slot_cn, slot_g, clsval, clslead, leadcol,
-        minp, nidv, knew, itemj, clist, klist, kval, krep, bmc, bmf, xid, dsc;
+        minp, nidv, knew, itemj, clist, klist, kval, krep, bmc, bmf, cbm, kbm, xid, dsc;
     int Dp, cols_l, idcap, total;
 };
 

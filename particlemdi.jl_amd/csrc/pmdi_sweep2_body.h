@@ -120,7 +120,7 @@ constexpr unsigned INFU = 0xFFFFFFFFu;
 constexpr int PMDI_S2_REQUEUE = 1;   // err code: sweep this chain again with the general kernel
 
 // per-dataset scalars (ints in LDS)
-enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_ND, DS_NK, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_FOLLOW, DS_DIRTY, DS_NEEDMASK, DS_CHANGED, DS_COUNT = 16 };
+enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_NDX, DS_UNUSED, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_FOLLOW, DS_DIRTY, DS_NEEDMASK, DS_CHANGED, DS_COUNT = 16 };
 // shared scalars
 enum { SC_FAIL = 0, SC_RES, SC_PSTAR, SC_NLEAF, SC_NPROG, SC_JS, SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3, SC_COUNT = 16 };
 
@@ -165,6 +165,7 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     L.minp = take(CLS * N * 4); L.nidv = take(CLS * N * 4); L.knew = take(CLS * N); L.itemj = take(CLS * N);
     L.clist = take(NDCAP * 2); L.klist = take(CLS * N * 4); L.kval = take(CLS * N * 4); L.krep = take(CLS * N * 4);
     L.bmc = take((P / 64 + 1) * 8); L.bmf = take((P / 64 + 1) * 8);
+    L.cbm = take(((idcap + 63) / 64) * 8); L.kbm = take(((CLS * N + 63) / 64) * 8);
     L.xid = take(XCAP * 4);
     L.dsc = take(DS_COUNT * 4);
     L.ds_stride = o;
@@ -364,6 +365,8 @@ struct Sweep2 {
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
     unsigned cslp;              // class slot of the lane's particles per dataset, 2 bits each: bit offset 2 * (k * PPL + u)
     RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
+    double pend_g;              // owner wave, lane 0: the prefix constant of the slot refreshed by the last step's fast path, on its way
+    int pend_slot;              // ... and which slot it belongs to (-1: none)
     // ---- uniform ----
     const PM2_CONST SweepArgs *ap;
     int tid, lane, wave, chain;
@@ -424,7 +427,7 @@ struct Sweep2 {
 
     // ---- cluster cache (owner wave) -------------------------------------------------------------------------------------------
     // load the statistics of cluster `id` into slot s0 (uniform) of the owner wave: lane = feature
-    PM2_DEV void cache_fill(const DV &v, int k, int s0, double sg, double bt, int cnv)
+    PM2_DEV void cache_fill(const DV &v, int k, int s0, double sg, double bt, int cnv, bool defer = false)
     {
         double mu, lam;
         pmdi_arith::gauss_ml(cnv, sg, bt, mu, lam);
@@ -434,7 +437,10 @@ struct Sweep2 {
         if (lane < v.D) v.ta_row(s0)[lane] = 0.5 * log(lam / ((double)cnv + 1.0));            // gaussian_cluster.jl:45
         if (lane == 0) {
             lds<int>(v.base + L.slot_cn)[s0] = cnv;
-            lds<double>(v.base + L.slot_g)[s0] = (double)v.dsc()[DS_NFLAG] * PM2_G(const double, ap->ds[k].gtab)[cnv];   // :38-40
+            const double g = PM2_G(const double, ap->ds[k].gtab)[cnv];            // gaussian_cluster.jl:38-40
+            // (deferred: the load stays in flight; the next cluster phase of this wave writes the value where the ordered sums read it)
+            if (defer) { pend_g = g; pend_slot = s0; }
+            else lds<double>(v.base + L.slot_g)[s0] = (double)v.dsc()[DS_NFLAG] * g;
         }
     }
 
@@ -458,6 +464,8 @@ struct Sweep2 {
         for (int e = lane; e < CLS * N; e += 64) lds<unsigned>(v.base + L.minp)[e] = INFU;
         for (int e = lane; e < P / 64 + 1; e += 64) { lds<u64>(v.base + L.bmc)[e] = 0; lds<u64>(v.base + L.bmf)[e] = 0; }
         for (int e = lane; e < NS; e += 64) lds<int>(v.base + L.slot_id)[e] = 0;
+        for (int e = lane; e < (v.idcap + 63) / 64; e += 64) lds<u64>(v.base + L.cbm)[e] = 0;
+        for (int e = lane; e < (CLS * N + 63) / 64; e += 64) lds<u64>(v.base + L.kbm)[e] = 0;
         if (lane < 64) { lab[lane] = 0x7fffffff; lab[64 + lane] = 0; lab[128 + lane] = 0; fl[lane] = (lane < D) ? (flags ? flags[lane] : (u8)1) : (u8)0; }
         // what lives in the arena: new_id (:167), the per-id scratch beyond idcap, the column tables beyond cols_l
         {
@@ -520,7 +528,7 @@ struct Sweep2 {
         if (lane == 0) {
             int nf = 0;
             for (int q = 0; q < D; ++q) nf += fl[q];
-            dsc[DS_NFLAG] = nf; dsc[DS_MAXID] = nu + 1; dsc[DS_NCLS] = 1; dsc[DS_NCOL] = 1; dsc[DS_ND] = 0; dsc[DS_NK] = 0; dsc[DS_NX] = 0;
+            dsc[DS_NFLAG] = nf; dsc[DS_MAXID] = nu + 1; dsc[DS_NCLS] = 1; dsc[DS_NCOL] = 1; dsc[DS_NDX] = 0; dsc[DS_NX] = 0;
             dsc[DS_DIRTY] = 1; dsc[DS_CHANGED] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_NEEDMASK] = 0; dsc[DS_NCLONE] = 0;
             lds<int>(v.base + L.clsval)[0] = 1; lds<int>(v.base + L.clslead)[0] = 0; lds<int>(v.base + L.leadcol)[0] = 0;
         }
@@ -529,7 +537,7 @@ struct Sweep2 {
 
     // ---- phase A (owner wave of dataset k): log-predictives of the clusters the class leaders can reach (src/pmdi.jl:218-220,:232),
     //      the mutation CDF of every particle class (:231-248) -------------------------------------------------------------------------
-    PM2_DEV void phase_a(int k, double x, int i_obs, long long pos)
+    PM2_DEV void phase_a(int k, double x, int ns0_cur, long long pos)
     {
         const DV v = view(k);
         const auto &d = ap->ds[k];
@@ -541,6 +549,7 @@ struct Sweep2 {
         u8 *itemj = lds<u8>(v.base + L.itemj);
         int *slot_id = lds<int>(v.base + L.slot_id);
         int *xid = lds<int>(v.base + L.xid);
+        if (lane == 0 && pend_slot >= 0) { lds<double>(v.base + L.slot_g)[pend_slot] = (double)dsc[DS_NFLAG] * pend_g; pend_slot = -1; }
         // -- A1: the clusters the class leaders' columns hold; their cache slots (stable while a cluster stays reachable).  Skipped
         // while nothing it depends on has changed (phase C and the resampling say so): most steps of a settled chain
         unsigned needmask = 0;
@@ -638,7 +647,17 @@ struct Sweep2 {
         if (lane < NS && ((needmask >> lane) & 1u)) {
             const double *ta = v.ta_row(lane), *tb = v.tb_row(lane);
             double out = lds<double>(v.base + L.slot_g)[lane];
-            for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
+            if (dsc[DS_NFLAG] == D) {           // all features on: fetch eight features' terms, then add them in order
+                for (int q0 = 0; q0 < D; q0 += 8) {
+                    double ra[8], rb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int q = (q0 + u < D) ? q0 + u : D - 1; ra[u] = ta[q]; rb[u] = tb[q]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (q0 + u < D) { out += ra[u]; out -= rb[u]; }
+                }
+            } else {
+                for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
+            }
             lp[lane] = out;
         }
         // uncached reachable clusters, XR per round: statistics from the pool, both terms on the fly
@@ -682,7 +701,14 @@ struct Sweep2 {
                 wv[lane] = val;
                 PM2_WAVE_BARRIER();
                 double m = val;
-                for (int j = 0; j < N; ++j) { const double t = wv[gbase + j]; m = (t > m) ? t : m; }
+                {
+                    int j = 0;
+                    for (; j + 4 <= N; j += 4) {      // four LDS reads in flight
+                        const double t0 = wv[gbase + j], t1 = wv[gbase + j + 1], t2 = wv[gbase + j + 2], t3 = wv[gbase + j + 3];
+                        m = (t0 > m) ? t0 : m; m = (t1 > m) ? t1 : m; m = (t2 > m) ? t2 : m; m = (t3 > m) ? t3 : m;
+                    }
+                    for (; j < N; ++j) { const double t = wv[gbase + j]; m = (t > m) ? t : m; }
+                }
                 double e = val - m;
                 e = exp(e);
                 e = e * (valid ? pik[nn] : 0.0);
@@ -690,7 +716,17 @@ struct Sweep2 {
                 PM2_WAVE_BARRIER();
                 const double e0v = wv[64 + gbase];
                 double s_ = 0.0;
-                for (int j = 1; j < N; ++j) { const double t = wv[64 + gbase + j]; if (j <= nn) s_ = (j == 1) ? t : s_ + t; }
+                {
+                    int j = 1;
+                    for (; j + 4 <= N; j += 4) {      // loads first, then the ordered adds
+                        const double t0 = wv[64 + gbase + j], t1 = wv[64 + gbase + j + 1], t2 = wv[64 + gbase + j + 2], t3 = wv[64 + gbase + j + 3];
+                        if (j <= nn) s_ = (j == 1) ? t0 : s_ + t0;
+                        if (j + 1 <= nn) s_ = s_ + t1;
+                        if (j + 2 <= nn) s_ = s_ + t2;
+                        if (j + 3 <= nn) s_ = s_ + t3;
+                    }
+                    for (; j < N; ++j) { const double t = wv[64 + gbase + j]; if (j <= nn) s_ = (j == 1) ? t : s_ + t; }
+                }
                 const double c = (nn == 0) ? e : e0v + s_;
                 PM2_WAVE_BARRIER();
                 wv[lane] = c;
@@ -729,7 +765,7 @@ struct Sweep2 {
             }
         }
 #endif
-        if (lane == 0) dsc[DS_NS0] = PM2_G(const int, ap->s_in)[((size_t)chain * K + k) * n + i_obs];     // reference trajectory (:262)
+        if (lane == 0) dsc[DS_NS0] = ns0_cur;             // reference trajectory (:262), fetched a step ago
         (void)pos;
     }
 
@@ -742,25 +778,81 @@ struct Sweep2 {
         const int D = d.D;
         int *dsc = v.dsc();
         const u8 *fl = flk(k);
-        const int nd = PM2_UNI(dsc[DS_ND]), nk = PM2_UNI(dsc[DS_NK]);
         const int maxid = PM2_UNI(dsc[DS_MAXID]), ncol = PM2_UNI(dsc[DS_NCOL]), ncls = PM2_UNI(dsc[DS_NCLS]);
         u16 *clist = lds<u16>(v.base + L.clist);
         int *klist = lds<int>(v.base + L.klist), *kval = lds<int>(v.base + L.kval), *krep = lds<int>(v.base + L.krep);
+        // the chosen clusters and the touched keys, from the bitmaps the particle phase marked, as dense lists
+        int nd = 0, nk = 0, nd_low = 0;
+        {
+            u64 *cbm = lds<u64>(v.base + L.cbm), *kbm = lds<u64>(v.base + L.kbm);
+            const u64 below = (1ull << lane) - 1ull;
+            for (int w = 0; w < (v.idcap + 63) / 64; ++w) {
+                const u64 bits = cbm[w];
+                if ((bits >> lane) & 1ull) clist[nd + pm2_popc64(bits & below)] = (u16)(w * 64 + lane);
+                nd += pm2_popc64(bits);
+            }
+            const int ndx = PM2_UNI(dsc[DS_NDX]);
+            if (nd + ndx > NDCAP) { if (lane == 0) sc()[SC_FAIL] = 3; return false; }          // too many distinct chosen clusters
+            nd_low = nd;                      // (entries nd_low.. are the overflow list: ids beyond the LDS tables, filled from the top)
+            nd += ndx;
+            for (int w = 0; w < (CLS * N + 63) / 64; ++w) {
+                const u64 bits = kbm[w];
+                if ((bits >> lane) & 1ull) klist[nk + pm2_popc64(bits & below)] = w * 64 + lane;
+                nk += pm2_popc64(bits);
+            }
+            PM2_WAVE_BARRIER();
+            for (int w = lane; w < (v.idcap + 63) / 64; w += 64) cbm[w] = 0;
+            for (int w = lane; w < (CLS * N + 63) / 64; w += 64) kbm[w] = 0;
+        }
+        auto chosen = [&](int e) -> int { return (int)(e < nd_low ? clist[e] : clist[NDCAP - 1 - (e - nd_low)]); };
         unsigned *minp = lds<unsigned>(v.base + L.minp);
         u64 *bmc = lds<u64>(v.base + L.bmc), *bmf = lds<u64>(v.base + L.bmf);
-        if (nd > NDCAP) { if (lane == 0) sc()[SC_FAIL] = 3; return false; }          // too many distinct chosen clusters
         // the statistics of the first chosen cluster (the only one in most steps), on their way while the bookkeeping runs
         double pf_sg = 0.0, pf_bt = 0.5;
         if (nd > 0 && lane < D) {
             auto sb0 = PM2_G(const double, v.ar.sb());
-            const int c0 = clist[0];
+            const int c0 = chosen(0);
             pf_sg = sb0[((size_t)c0 * D + lane) * 2]; pf_bt = sb0[((size_t)c0 * D + lane) * 2 + 1];
+        }
+        // -- C0: the step of a settled chain, most of the time: one class, every particle drew the same label and the same cluster,
+        // all references of that cluster were chosen (so it is updated in place, :286-290), the (class, label) key is known and keeps
+        // the class its value: no clone, no new class, no column changes -- the statistics, the cache and the idle state of the census
+        if (nd == 1 && nk == 1 && ncls == 1 && ap->q1 == 0) {
+            const int c = chosen(0), key = klist[0];
+            const int v0 = lds<int>(v.base + L.nidv)[key];
+            if (v.ncop_get(c) == v.counts_get(c) && v0 > 0 && v0 == lds<int>(v.base + L.clsval)[0]) {
+                const int nnew = v.cn_get(c) + 1;
+                const int s0 = v.slot_of(c);
+                double sg = pf_sg, bt = pf_bt;
+                const bool on = lane < D && fl[lane];
+                if (on) {
+                    pmdi_arith::gauss_add_sb(x, nnew, sg, bt);
+                    auto sb = PM2_G(double, v.ar.sb());
+                    sb[((size_t)c * D + lane) * 2] = sg; sb[((size_t)c * D + lane) * 2 + 1] = bt;
+                }
+                if (s0 != NONE8) cache_fill(v, k, s0, sg, bt, nnew, true);
+                for (int cc = lane; cc < ncol; cc += 64) v.cmask_set(cc, 0);
+                PM2_WAVE_BARRIER();
+                if (lane == 0) {
+                    v.cn_set(c, nnew); v.ncop_set(c, 0); v.firstp_set(c, 0x7fffffff);
+                    minp[key] = INFU;
+                    long long *st = stat();
+                    pm2_atomic_add((u64 *)&st[0], (u64)maxid);
+                    pm2_atomic_add((u64 *)&st[4], (u64)1);
+                    pm2_atomic_add((u64 *)&st[5], (u64)1);
+                    pm2_atomic_max((u64 *)&st[3], (u64)maxid);
+                    long long *w_ = wk(k);
+                    w_[WK_EVAL] += dsc[DS_NNEED]; w_[WK_UPD] += 1;
+                    dsc[DS_NDX] = 0; dsc[DS_NCLONE] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_DIRTY] = 0; dsc[DS_CHANGED] = 0;
+                }
+                return true;
+            }
         }
         // -- C1: clone or in place (:286-299): a chosen cluster all of whose references were chosen is updated in place
         for (int e0 = 0; e0 < nd; e0 += 64) {
             const int e = e0 + lane;
             if (e < nd) {
-                const int c = clist[e];
+                const int c = chosen(e);
                 if (v.ncop_get(c) != v.counts_get(c)) { const int fp = v.firstp_get(c); pm2_atomic_or(&bmc[fp >> 6], 1ull << (fp & 63)); }
             }
         }
@@ -771,7 +863,7 @@ struct Sweep2 {
         for (int e0 = 0; e0 < nd; e0 += 64) {
             const int e = e0 + lane;
             if (e < nd) {
-                const int c = clist[e];
+                const int c = chosen(e);
                 const int ncp = v.ncop_get(c), fp = v.firstp_get(c);
                 const int cnt_c = v.counts_get(c);
                 const bool needs = ncp != cnt_c;
@@ -919,7 +1011,7 @@ struct Sweep2 {
         {
             auto sb = PM2_G(double, v.ar.sb());
             for (int e = 0; e < nd; ++e) {
-                const int c = clist[e];
+                const int c = chosen(e);
                 const int t = v.tgt_get(c);
                 const int nnew = v.cn_get(t);
                 const int s0 = v.slot_of(c);
@@ -935,7 +1027,7 @@ struct Sweep2 {
         PM2_WAVE_BARRIER();
         for (int e0 = 0; e0 < nd; e0 += 64) {
             const int e = e0 + lane;
-            if (e < nd) { const int c = clist[e]; v.ncop_set(c, 0); v.firstp_set(c, 0x7fffffff); }
+            if (e < nd) { const int c = chosen(e); v.ncop_set(c, 0); v.firstp_set(c, 0x7fffffff); }
         }
         for (int j0 = 0; j0 < nk; j0 += 64) { const int j = j0 + lane; if (j < nk) minp[klist[j]] = INFU; }
         for (int w = lane; w < P / 64 + 1; w += 64) { bmc[w] = 0; bmf[w] = 0; }
@@ -949,7 +1041,7 @@ struct Sweep2 {
             pm2_atomic_max((u64 *)&st[3], (u64)(maxid + nclone));        // max_id: after the copy-on-write, before any renumbering
             long long *w_ = wk(k);
             w_[WK_EVAL] += dsc[DS_NNEED]; w_[WK_UPD] += nd; w_[WK_CLONE] += nclone; w_[WK_SPLITS] += ncol_new - ncol;
-            dsc[DS_MAXID] = maxid + nclone; dsc[DS_NCLS] = nrep; dsc[DS_NCOL] = ncol_new; dsc[DS_ND] = 0; dsc[DS_NK] = 0; dsc[DS_NCLONE] = nclone;
+            dsc[DS_MAXID] = maxid + nclone; dsc[DS_NCLS] = nrep; dsc[DS_NCOL] = ncol_new; dsc[DS_NDX] = 0; dsc[DS_NCLONE] = nclone;
             // the particles have something to follow when a column was split or written, or when the class slots move: not when the
             // step had one class, one (class, label) key and no clone (the key's class is slot 0 again)
             dsc[DS_FOLLOW] = (nclone != 0 || ncls != 1 || nk != 1) ? 1 : 0;
@@ -962,26 +1054,35 @@ struct Sweep2 {
         return true;
     }
 
-    // ---- the census of one particle's draw, aggregated over the lanes of the wave that drew the same (class, column, label) -------
-    PM2_DEV void census(const DV &v, int r, int cl, int ns, int c, int p)
+    // ---- the census of a lane's draw (`mult` of its particles drew the same class, column and label; p the first of them),
+    //      aggregated over the lanes of the wave that drew the same.  Nothing here waits for an answer: the chosen clusters and the
+    //      touched (class, label) keys are marked in bitmaps that phase C reads back; only a cluster id beyond the LDS tables
+    //      (rare) takes the returning path into the overflow list. ----------------------------------------------------------------
+    PM2_DEV void census(const DV &v, bool active, int mult, int r, int cl, int ns, int c, int p)
     {
         int *dsc = v.dsc();
-        const int key3 = (r * P + cl) * N + ns;
-        u64 rem = ~0ull;
+        const int key3 = ((r * P + cl) * N + ns) * 8 + mult;
+        u64 rem = PM2_BALLOT(active);
         while (rem) {
             const int l0 = pm2_ffs64(rem) - 1;
             const int k0 = readlane_i(key3, l0);
-            const u64 m = PM2_BALLOT(key3 == k0);
+            const u64 m = PM2_BALLOT(active && key3 == k0);
             if (lane == l0) {
-                const int cnt = pm2_popc64(m);
+                const int cnt = pm2_popc64(m) * mult;
                 // chosen cluster: copies and first particle (:279)
-                const int old = v.firstp_min(c, p);          // (idle value INF: the first toucher of a cluster sees it and lists the cluster)
-                v.ncop_add(c, cnt);
-                if (old == 0x7fffffff) { const int idx = pm2_atomic_add(&dsc[DS_ND], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[idx] = (u16)c; }
+                if (c < v.idcap) {
+                    pm2_atomic_add(lds<int>(v.base + L.ncop) + c, cnt);
+                    pm2_atomic_min(lds<int>(v.base + L.firstp) + c, p);
+                    pm2_atomic_or(lds<u64>(v.base + L.cbm) + (c >> 6), 1ull << (c & 63));
+                } else {
+                    const int old = pm2_atomic_min(v.ar.firstp() + c, p);       // (idle value INF: the first toucher lists the cluster)
+                    pm2_atomic_add(v.ar.ncop() + c, cnt);
+                    if (old == 0x7fffffff) { const int idx = pm2_atomic_add(&dsc[DS_NDX], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[NDCAP - 1 - idx] = (u16)c; }
+                }
                 // (class, label) key: first particle, with its column
                 const int key = r * N + ns;
-                const unsigned oldk = pm2_atomic_min(&lds<unsigned>(v.base + L.minp)[key], ((unsigned)p << 16) | (unsigned)cl);
-                if (oldk == INFU) { const int idx = pm2_atomic_add(&dsc[DS_NK], 1); lds<int>(v.base + L.klist)[idx] = key; }
+                pm2_atomic_min(&lds<unsigned>(v.base + L.minp)[key], ((unsigned)p << 16) | (unsigned)cl);
+                pm2_atomic_or(lds<u64>(v.base + L.kbm) + (key >> 6), 1ull << (key & 63));
                 // labels chosen on this column
                 v.cmask_or(cl, 1ull << ns);
             }
@@ -1394,29 +1495,42 @@ struct Sweep2 {
         PM2_BARRIER();
         PH2(1);
 
-        // the observation row of the owner wave's dataset, one step ahead (lane = feature)
+        // the observation row of the owner wave's dataset and the reference trajectory's label there, one step ahead (lane = feature);
+        // the shuffled order two steps ahead, so that the row's address never waits for it
         double xnext = 0.0;
+        int ns0_next = 0;
         int i_next = order[n1 - 1];
-        if (owner && lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+        int i_next2 = (n1 < n) ? order[n1] : 0;
+        if (owner) {
+            if (lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+            ns0_next = PM2_G(const int, a.s_in)[((size_t)chain * K + wave) * n + i_next];
+        }
+        pend_slot = -1; pend_g = 0.0;
         int failed = 0;
         for (long long pos = n1 - 1; pos < n; ++pos) {
             PM2_LAUNDER(ap, SweepArgs);
             PM2_FRESH_VGPR(tid); PM2_FRESH_VGPR(lane);
-            const int i = i_next;
             const double x = xnext;
+            const int ns0_cur = ns0_next;
             if (pos + 1 < n) {
-                i_next = order[pos + 1];
-                if (owner && lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+                i_next = i_next2;
+                if (owner) {
+                    if (lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+                    ns0_next = PM2_G(const int, a.s_in)[((size_t)chain * K + wave) * n + i_next];
+                }
+                if (pos + 2 < n) i_next2 = order[pos + 2];
             }
             // ---- cluster phase: the K datasets side by side, one owner wave each
             PH2(1);
-            if (owner) phase_a(wave, x, i, pos);
+            if (owner) phase_a(wave, x, ns0_cur, pos);
             PH2(2);
             PM2_BARRIER();
             PH2(3);
             if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
             // ---- particle phase (all lanes, all datasets): allocation draw (:251-265), census, weights (:227,:245), Phi (:312-314).
-            // (Neither the datasets nor the lane's particles are unrolled: the step has to stay inside the instruction cache.)
+            // Per dataset: the class rows of the lane's particles are read together; only particles whose row is not one-hot go
+            // through the random draw (one instance of the generator, not unrolled: the step has to stay inside the instruction
+            // cache); the chosen clusters are read together; particles of the lane that drew the same are counted once.
             unsigned nsp[PPL];                                                  // the labels a particle drew, a byte per dataset
 #pragma unroll
             for (int u = 0; u < PPL; ++u) nsp[u] = 0;
@@ -1424,32 +1538,43 @@ struct Sweep2 {
             for (int k = 0; k < K; ++k) {
                 const DV v = view(k);
                 const int ns0 = v.dsc()[DS_NS0];
-                unsigned pk[NCP];
+                int cl_[PPL], r_[PPL], c_[PPL];
+                RegArr<int, PPL> nsv;
+                double inc_[PPL];
+                bool draw_any = false;
 #pragma unroll
-                for (int j2 = 0; j2 < NCP; ++j2) pk[j2] = colp[k * NCP + j2];
-                unsigned packed = 0;
-#pragma nounroll
                 for (int u = 0; u < PPL; ++u) {
                     const int p = tid * PPL + u;
-                    const int r = csl_get(k, u);
-                    unsigned pw = pk[0];
-#pragma unroll
-                    for (int j2 = 1; j2 < NCP; ++j2) pw = ((u >> 1) == j2) ? pk[j2] : pw;
-                    const int cl = (int)((pw >> ((u & 1) * 16)) & 0xffffu);
-                    const double *row = v.cdf_row(r);
+                    r_[u] = csl_get(k, u);
+                    cl_[u] = (int)((colp[k * NCP + (u >> 1)] >> ((u & 1) * 16)) & 0xffffu);
+                    const double *row = v.cdf_row(r_[u]);
                     const int hot = (int)row[N + 1];
-                    int ns = 0;
-                    if (p == 0) ns = ns0;                                       // reference trajectory (:262)
-                    else if (hot >= 0) ns = hot;                                // one-hot CDF: no random number needed
-                    else {
-                        const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
-                        // first label whose CDF exceeds u (:252-260) = the number of leading entries that do not exceed it
-                        for (int t = 0; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
+                    inc_[u] = row[N];
+                    const int ns = (p == 0) ? ns0 : hot;                        // reference trajectory (:262); one-hot CDF: no random number needed
+                    nsv.set(u, ns);
+                    draw_any |= ns < 0;
+                }
+                if (PM2_BALLOT(draw_any)) {
+#pragma nounroll
+                    for (int u = 0; u < PPL; ++u) {
+                        if (nsv[u] < 0) {
+                            const int p = tid * PPL + u;
+                            const double *row = v.cdf_row(csl_get(k, u));
+                            const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
+                            // first label whose CDF exceeds u (:252-260) = the number of leading entries that do not exceed it
+                            int ns = 0;
+                            for (int t = 0; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
+                            nsv.set(u, ns);
+                        }
                     }
-                    lw_set(u, lw_get(u) + row[N]);                              // logweight[p] += increment (:227,:245), dataset order
-                    const int c = v.tab_get(cl, ns);                            // sstar_id (:264)
+                }
+                unsigned packed = 0;
 #pragma unroll
-                    for (int j2 = 0; j2 < PPL; ++j2) nsp[j2] |= (u == j2) ? ((unsigned)ns << (8 * k)) : 0u;
+                for (int u = 0; u < PPL; ++u) {
+                    const int ns = nsv[u];
+                    lw.set(u, lw[u] + inc_[u]);                                 // logweight[p] += increment (:227,:245), dataset order
+                    c_[u] = v.tab_get(cl_[u], ns);                              // sstar_id (:264)
+                    nsp[u] |= (unsigned)ns << (8 * k);
                     packed |= (unsigned)ns << (8 * (u & 3));
                     if ((u & 3) == 3 || u == PPL - 1) {                         // sstar[p, i, k] (:265), four particles per store
                         u8 *ss = v.ar.sstar() + (size_t)pos * P + (size_t)tid * PPL + (u & ~3);
@@ -1458,7 +1583,19 @@ struct Sweep2 {
                         else *PM2_G(u8, ss) = (u8)packed;
                         packed = 0;
                     }
-                    census(v, r, cl, ns, c, p);
+                }
+#pragma unroll
+                for (int u = 0; u < PPL; ++u) {
+                    // particles of the lane that drew the same class, column and label are counted with the first of them
+                    bool dup = false;
+                    int mult = 0;
+#pragma unroll
+                    for (int u2 = 0; u2 < PPL; ++u2) {
+                        const bool same = r_[u2] == r_[u] && cl_[u2] == cl_[u] && nsv[u2] == nsv[u];
+                        if (u2 < u) dup |= same;
+                        if (u2 >= u) mult += same ? 1 : 0;
+                    }
+                    census(v, !dup, mult, r_[u], cl_[u], nsv[u], c_[u], tid * PPL + u);
                 }
             }
             if (K > 1) {                                                        // Phi_upweight! (src/misc.jl:50-59)
