@@ -145,7 +145,7 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_args4, d_args5, d_requeue, d_requeue_total, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_args4, d_args5, d_requeue, d_requeue_total, d_handed, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
     int ksplit = 0;
     int ksplit_batch = 0;        // split mode: chain slots per launch when n_chains * K workgroups are not resident at once (0 = one launch)
     bool have_order = false;
@@ -158,6 +158,7 @@ struct pmdi_handle {
     // settled-chain kernel (pmdi_sweep2.hip): takes the light group of a sweep when the configuration is one it is built for
     bool s2_ok = false;
     S2Layout s2{};
+    int sweep_no = 0;
     int err_keep = 0;            // set by the device-resident driver around its sweeps (pmdi_gibbs_step)
     int children = 0;            // live pmdi_gibbs / cluster-batch objects: pmdi_destroy refuses while > 0
     // feature selection
@@ -232,6 +233,8 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.s2 = h->s2;
     a.requeue = h->s2_ok ? (int *)h->d_requeue.p : nullptr;
     a.requeue_total = h->s2_ok ? (long long *)h->d_requeue_total.p : nullptr;
+    a.handed = h->s2_ok ? (int *)h->d_handed.p : nullptr;
+    a.sweep_no = h->sweep_no;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
     for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
@@ -348,7 +351,8 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
     if (C > 1 || h->split) {
         const long long steps = (a.n - a.n1 + 1) * (long long)a.K;
         e = pmdi_launch_chain_order((const long long *)h->d_cost.p, (int *)h->d_lorder.p, a.stats,
-                                    h->split ? (unsigned char *)h->d_group.p : nullptr, h->light_ids * steps, C, st);
+                                    h->split ? (unsigned char *)h->d_group.p : nullptr, h->light_ids * steps, C, st,
+                                    h->s2_ok ? (const int *)h->d_handed.p : nullptr, h->sweep_no);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "chain-order launch: %s", hipGetErrorString(e));
         h->have_order = true;
     }
@@ -374,7 +378,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->ring) (void)hipHostFree(h->ring);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_args4, &h->d_args5, &h->d_requeue, &h->d_requeue_total, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_args4, &h->d_args5, &h->d_requeue, &h->d_requeue_total, &h->d_handed, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
                       &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -650,8 +654,12 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)) ||
         (rc = h->d_args4.ensure(sizeof(SweepArgs))) || (rc = h->d_args5.ensure(sizeof(SweepArgs))) || (rc = h->d_requeue.ensure((size_t)C * 4)) ||
-        (rc = h->d_requeue_total.ensure(4 * 8)))
+        (rc = h->d_requeue_total.ensure(4 * 8)) || (rc = h->d_handed.ensure((size_t)C * 4)))
         return bail(rc);
+    {
+        std::vector<int> never((size_t)C, -1000);
+        if (hipMemcpy(h->d_handed.p, never.data(), (size_t)C * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "memcpy failed"));
+    }
     if (hipMemset(h->d_requeue.p, 0, (size_t)C * 4) != hipSuccess || hipMemset(h->d_requeue_total.p, 0, 32) != hipSuccess)
         return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));
     {   // pinned staging ring of the argument blocks (asynchronous launches); without it the copies fall back to pageable memory

@@ -132,6 +132,9 @@ struct SweepArgs {
     int rank_lo, rank_hi;       // ... and whose position in the launch order is in [rank_lo, rank_hi)
     S2Layout s2;                // settled-chain kernel: its LDS layout (cols_l / idcap = columns / cluster ids kept in LDS)
     int *requeue;               // [chain] 1: the settled-chain kernel gave the chain back (it does not fit its tables): sweep it again
+    int *handed;                // [chain] number of the sweep in which the chain was last given back (such a chain goes to the general
+                                // kernel directly for the next few sweeps: it tends to be given back again), or null
+    int sweep_no;               // this sweep's number (per handle)
     long long *requeue_total;   // [4] chains given back so far, by reason (reachable clusters, chosen clusters, classes), and in total
     int requeue_only;           // 1: this launch of the general kernel sweeps exactly those chains
     int slot_base;              // split mode launched in residency-sized batches: first chain slot of this launch
@@ -205,7 +208,7 @@ hipError_t pmdi_launch_cluster_add(const ClusterBatchArgs &a, hipStream_t stream
 hipError_t pmdi_launch_cluster_logprob(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_t stream);
 hipError_t pmdi_launch_chain_order(const long long *cost, int *order, const long long *stats, unsigned char *group_flag,
-                                   long long light_ops_max, int n_chains, hipStream_t stream);
+                                   long long light_ops_max, int n_chains, hipStream_t stream, const int *handed = nullptr, int sweep_no = 0);
 hipError_t pmdi_launch_featsel(const FeatSelArgs &a, int n_chains, hipStream_t stream);
 hipError_t pmdi_launch_psm_counts(const unsigned char *samples, long long S, int K, long long n, long long row_lo, long long row_hi,
                                   int *counts, hipStream_t stream);

@@ -2181,13 +2181,15 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 // first (longest-processing-time order: the few slow chains start at once and the many fast ones
 // fill in behind them, instead of a slow chain starting last and leaving the GPU idle).
 __global__ void chain_order_kernel(const long long *cost, int *order, const long long *stats, unsigned char *group_flag,
-                                   long long light_ops_max, int n_chains)
+                                   long long light_ops_max, int n_chains, const int *handed, int sweep_no)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_chains) return;
     // group of the next sweep: a chain is light when its sweep met few live clusters per step
     // (stats[0] = sum over steps of the live-cluster count, the reference's n_operations)
-    if (group_flag) group_flag[c] = (stats[(size_t)c * 8] > light_ops_max) ? 1 : 0;
+    // ... and was not given back by the settled-chain kernel in one of the last three sweeps (a chain in a state with many
+    // particle classes tends to stay there for a while: it goes to the general kernel directly instead of being swept twice)
+    if (group_flag) group_flag[c] = (stats[(size_t)c * 8] > light_ops_max || (handed && sweep_no - handed[c] < 3)) ? 1 : 0;
     const long long mine = cost[c];
     int rank = 0;
     for (int j = 0; j < n_chains; ++j) {
@@ -2200,10 +2202,10 @@ __global__ void chain_order_kernel(const long long *cost, int *order, const long
 }  // namespace
 
 hipError_t pmdi_launch_chain_order(const long long *cost, int *order, const long long *stats, unsigned char *group_flag,
-                                   long long light_ops_max, int n_chains, hipStream_t stream)
+                                   long long light_ops_max, int n_chains, hipStream_t stream, const int *handed, int sweep_no)
 {
     hipLaunchKernelGGL(chain_order_kernel, dim3((n_chains + 255) / 256), dim3(256), 0, stream, cost, order, stats, group_flag,
-                       light_ops_max, n_chains);
+                       light_ops_max, n_chains, handed, sweep_no);
     return hipGetLastError();
 }
 

@@ -103,6 +103,16 @@ __device__ __forceinline__ int pm2_ffs64(unsigned long long x) { return __ffsll(
 
 namespace pmdi_s2 {
 
+// A/B builds only (-DPM2_DETAIL_TIMERS, scripts/s2_probe.py): where inside the phases does lane 0 of wave 0 spend its cycles?  The
+// sixteen slots of the phase-timer record then hold: 0 need set, 1 terms, 2 ordered sums, 3 uncached clusters, 4 CDF, 5 class rows,
+// 6 random draws, 7 chosen clusters + history, 8 census, 9 Phi + maximum, 10 ESS sums, 11 lists of the bookkeeping phase, 12 its
+// fast path / clone, class and column work, 13 statistics, 15 clean-up, 14 the whole sweep
+#ifdef PM2_DETAIL_TIMERS
+#define PHD(i_) do { if (ap->phase && tid == 0) { const long long t_ = PM2_CLOCK(); lds<long long>(L.ph)[phd_cur] += t_ - phd_last; phd_last = t_; phd_cur = (i_); } } while (0)
+#else
+#define PHD(i_) do { } while (0)
+#endif
+
 typedef unsigned long long u64;
 typedef unsigned short u16;
 typedef unsigned char u8;
@@ -259,6 +269,7 @@ PM2_DEV double wave_min_d(double v)
     for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = (t < v) ? t : v; }
     return v;
 }
+PM2_DEV double prev_lane_d(double v) { const int lane = PM2_TID() & 63; return shfl_d(v, lane ? lane - 1 : 0); }
 // (the device's order: quad, quad pair, half row, row, then (r0 + r1) + (r2 + r3) over the four rows of sixteen lanes)
 PM2_DEV double wave_sum_d(double v)
 {
@@ -310,6 +321,8 @@ PM2_DEV double wave_max_d(double v)
     const double m01 = (r1 > r0) ? r1 : r0, m23 = (r3 > r2) ? r3 : r2;
     return (m23 > m01) ? m23 : m01;
 }
+// the value of the lane below (lane 0 keeps its own): one DPP shift across the whole wave, no LDS round trip
+PM2_DEV double prev_lane_d(double v) { return dpp_d<0x138>(v); }      // wave_shr:1
 PM2_DEV double wave_min_d(double v)
 {
     double t;
@@ -365,6 +378,10 @@ struct Sweep2 {
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
     unsigned cslp;              // class slot of the lane's particles per dataset, 2 bits each: bit offset 2 * (k * PPL + u)
     RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
+#ifdef PM2_DETAIL_TIMERS
+    long long phd_last;
+    int phd_cur;
+#endif
     double pend_g;              // owner wave, lane 0: the prefix constant of the slot refreshed by the last step's fast path, on its way
     int pend_slot;              // ... and which slot it belongs to (-1: none)
     // ---- uniform ----
@@ -549,6 +566,7 @@ struct Sweep2 {
         u8 *itemj = lds<u8>(v.base + L.itemj);
         int *slot_id = lds<int>(v.base + L.slot_id);
         int *xid = lds<int>(v.base + L.xid);
+        PHD(0);
         if (lane == 0 && pend_slot >= 0) { lds<double>(v.base + L.slot_g)[pend_slot] = (double)dsc[DS_NFLAG] * pend_g; pend_slot = -1; }
         // -- A1: the clusters the class leaders' columns hold; their cache slots (stable while a cluster stays reachable).  Skipped
         // while nothing it depends on has changed (phase C and the resampling say so): most steps of a settled chain
@@ -630,6 +648,7 @@ struct Sweep2 {
         if (lane == 0) { dsc[DS_NX] = nx; dsc[DS_NNEED] = nneed; dsc[DS_NEEDMASK] = (int)needmask; }
         PM2_WAVE_BARRIER();
         }
+        PHD(1);
         // -- A2: the per-feature terms: cached clusters need one log per feature (gaussian_cluster.jl:46-48), lane = feature
 #pragma nounroll
         for (int s = 0; s < NS; ++s) {
@@ -641,6 +660,7 @@ struct Sweep2 {
                 if (lane < D) v.tb_row(s)[lane] = tb;
             }
         }
+        PHD(2);
         // -- A3: ordered sums, one lane per cluster row (calc_logprob's loop, gaussian_cluster.jl:41-50, same terms, same order)
         double *lp = v.lp();
         PM2_WAVE_BARRIER();
@@ -660,6 +680,7 @@ struct Sweep2 {
             }
             lp[lane] = out;
         }
+        PHD(3);
         // uncached reachable clusters, XR per round: statistics from the pool, both terms on the fly
         for (int e0 = 0; e0 < nx; e0 += XR) {
             PM2_WAVE_BARRIER();
@@ -685,6 +706,7 @@ struct Sweep2 {
             }
         }
         PM2_WAVE_BARRIER();
+        PHD(4);
         // -- A4: mutation CDF per particle class (:231-248): lanes = (class, label); max / cumsum / normalise through a per-wave
         // exchange area.  The cumsum follows Julia's accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]) (n < 128).
         {
@@ -766,6 +788,7 @@ struct Sweep2 {
         }
 #endif
         if (lane == 0) dsc[DS_NS0] = ns0_cur;             // reference trajectory (:262), fetched a step ago
+        PHD(15);
         (void)pos;
     }
 
@@ -781,6 +804,7 @@ struct Sweep2 {
         const int maxid = PM2_UNI(dsc[DS_MAXID]), ncol = PM2_UNI(dsc[DS_NCOL]), ncls = PM2_UNI(dsc[DS_NCLS]);
         u16 *clist = lds<u16>(v.base + L.clist);
         int *klist = lds<int>(v.base + L.klist), *kval = lds<int>(v.base + L.kval), *krep = lds<int>(v.base + L.krep);
+        PHD(11);
         // the chosen clusters and the touched keys, from the bitmaps the particle phase marked, as dense lists
         int nd = 0, nk = 0, nd_low = 0;
         {
@@ -814,6 +838,7 @@ struct Sweep2 {
             const int c0 = chosen(0);
             pf_sg = sb0[((size_t)c0 * D + lane) * 2]; pf_bt = sb0[((size_t)c0 * D + lane) * 2 + 1];
         }
+        PHD(12);
         // -- C0: the step of a settled chain, most of the time: one class, every particle drew the same label and the same cluster,
         // all references of that cluster were chosen (so it is updated in place, :286-290), the (class, label) key is known and keeps
         // the class its value: no clone, no new class, no column changes -- the statistics, the cache and the idle state of the census
@@ -1005,6 +1030,7 @@ struct Sweep2 {
             fprintf(stderr, "\n");
         }
 #endif
+        PHD(13);
         // -- C4: deepcopy + cluster_add! of every distinct chosen cluster (:297,:300), lane = feature: (Sigma, beta) from the pool (the
         // first cluster's were fetched at the top of the phase), written to the pool; a cached cluster gets its mu, lambda and first
         // term refreshed in the owner wave's registers
@@ -1023,6 +1049,7 @@ struct Sweep2 {
                 if (s0 != NONE8 && t == c) cache_fill(v, k, s0, sg, bt, nnew);
             }
         }
+        PHD(15);
         // -- C5: the step's scratch back to its idle state; counters
         PM2_WAVE_BARRIER();
         for (int e0 = 0; e0 < nd; e0 += 64) {
@@ -1062,31 +1089,31 @@ struct Sweep2 {
     {
         int *dsc = v.dsc();
         const int key3 = ((r * P + cl) * N + ns) * 8 + mult;
-        u64 rem = PM2_BALLOT(active);
-        while (rem) {
-            const int l0 = pm2_ffs64(rem) - 1;
-            const int k0 = readlane_i(key3, l0);
-            const u64 m = PM2_BALLOT(active && key3 == k0);
-            if (lane == l0) {
-                const int cnt = pm2_popc64(m) * mult;
-                // chosen cluster: copies and first particle (:279)
-                if (c < v.idcap) {
-                    pm2_atomic_add(lds<int>(v.base + L.ncop) + c, cnt);
-                    pm2_atomic_min(lds<int>(v.base + L.firstp) + c, p);
-                    pm2_atomic_or(lds<u64>(v.base + L.cbm) + (c >> 6), 1ull << (c & 63));
-                } else {
-                    const int old = pm2_atomic_min(v.ar.firstp() + c, p);       // (idle value INF: the first toucher lists the cluster)
-                    pm2_atomic_add(v.ar.ncop() + c, cnt);
-                    if (old == 0x7fffffff) { const int idx = pm2_atomic_add(&dsc[DS_NDX], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[NDCAP - 1 - idx] = (u16)c; }
-                }
-                // (class, label) key: first particle, with its column
-                const int key = r * N + ns;
-                pm2_atomic_min(&lds<unsigned>(v.base + L.minp)[key], ((unsigned)p << 16) | (unsigned)cl);
-                pm2_atomic_or(lds<u64>(v.base + L.kbm) + (key >> 6), 1ull << (key & 63));
-                // labels chosen on this column
-                v.cmask_or(cl, 1ull << ns);
+        const u64 act = PM2_BALLOT(active);
+        if (act == 0) return;
+        // the whole wave drew the same (the rule in a settled chain): one lane speaks for it; otherwise every lane for itself -- the
+        // LDS atomics sort out equal addresses faster than an election loop over the distinct draws would
+        const int l0 = pm2_ffs64(act) - 1;
+        const int k0 = readlane_i(key3, l0);
+        const bool uni = PM2_BALLOT(active && key3 == k0) == act;
+        if (uni ? (lane == l0) : active) {
+            const int cnt = uni ? pm2_popc64(act) * mult : mult;
+            // chosen cluster: copies and first particle (:279)
+            if (c < v.idcap) {
+                pm2_atomic_add(lds<int>(v.base + L.ncop) + c, cnt);
+                pm2_atomic_min(lds<int>(v.base + L.firstp) + c, p);
+                pm2_atomic_or(lds<u64>(v.base + L.cbm) + (c >> 6), 1ull << (c & 63));
+            } else {
+                const int old = pm2_atomic_min(v.ar.firstp() + c, p);       // (idle value INF: the first toucher lists the cluster)
+                pm2_atomic_add(v.ar.ncop() + c, cnt);
+                if (old == 0x7fffffff) { const int idx = pm2_atomic_add(&dsc[DS_NDX], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[NDCAP - 1 - idx] = (u16)c; }
             }
-            rem &= ~m;
+            // (class, label) key: first particle, with its column
+            const int key = r * N + ns;
+            pm2_atomic_min(&lds<unsigned>(v.base + L.minp)[key], ((unsigned)p << 16) | (unsigned)cl);
+            pm2_atomic_or(lds<u64>(v.base + L.kbm) + (key >> 6), 1ull << (key & 63));
+            // labels chosen on this column
+            v.cmask_or(cl, 1ull << ns);
         }
     }
 
@@ -1109,7 +1136,7 @@ struct Sweep2 {
             double carry_in = 0.0;
             if (pass == 1) carry_in = tot[0];
             for (int t = 0; t < LPB; ++t) {
-                const double cin = shfl_d(acc, (lane + 63) & 63);
+                const double cin = prev_lane_d(acc);
                 if (mine && lib == t) {
                     double s = (t == 0) ? carry_in : cin;
 #pragma unroll
@@ -1462,7 +1489,12 @@ struct Sweep2 {
         // decision, [8] resampling, [9] finish, [14] whole sweep
         long long ph_last = 0;
         int ph_cur = 0;
+#ifdef PM2_DETAIL_TIMERS
+        phd_last = PM2_CLOCK(); phd_cur = 15;
+#define PH2(i_) do { } while (0)
+#else
 #define PH2(i_) do { if (a.phase && tid == 0) { const long long t_ = PM2_CLOCK(); lds<long long>(L.ph)[ph_cur] += t_ - ph_last; ph_last = t_; ph_cur = (i_); } } while (0)
+#endif
         if (a.phase && tid == 0) ph_last = PM2_CLOCK();
         PM2_BARRIER();
         if (tid == 0) {
@@ -1538,6 +1570,7 @@ struct Sweep2 {
             for (int k = 0; k < K; ++k) {
                 const DV v = view(k);
                 const int ns0 = v.dsc()[DS_NS0];
+                PHD(5);
                 int cl_[PPL], r_[PPL], c_[PPL];
                 RegArr<int, PPL> nsv;
                 double inc_[PPL];
@@ -1554,6 +1587,7 @@ struct Sweep2 {
                     nsv.set(u, ns);
                     draw_any |= ns < 0;
                 }
+                PHD(6);
                 if (PM2_BALLOT(draw_any)) {
 #pragma nounroll
                     for (int u = 0; u < PPL; ++u) {
@@ -1562,12 +1596,17 @@ struct Sweep2 {
                             const double *row = v.cdf_row(csl_get(k, u));
                             const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
                             // first label whose CDF exceeds u (:252-260) = the number of leading entries that do not exceed it
-                            int ns = 0;
-                            for (int t = 0; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
+                            int ns = 0, t = 0;
+                            for (; t + 4 <= N - 1; t += 4) {          // four LDS reads in flight
+                                const double a0 = row[t], a1 = row[t + 1], a2 = row[t + 2], a3 = row[t + 3];
+                                ns += ((a0 > u01) ? 0 : 1) + ((a1 > u01) ? 0 : 1) + ((a2 > u01) ? 0 : 1) + ((a3 > u01) ? 0 : 1);
+                            }
+                            for (; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
                             nsv.set(u, ns);
                         }
                     }
                 }
+                PHD(7);
                 unsigned packed = 0;
 #pragma unroll
                 for (int u = 0; u < PPL; ++u) {
@@ -1586,6 +1625,7 @@ struct Sweep2 {
                 }
 #pragma unroll
                 for (int u = 0; u < PPL; ++u) {
+                    PHD(8);
                     // particles of the lane that drew the same class, column and label are counted with the first of them
                     bool dup = false;
                     int mult = 0;
@@ -1598,6 +1638,7 @@ struct Sweep2 {
                     census(v, !dup, mult, r_[u], cl_[u], nsv[u], c_[u], tid * PPL + u);
                 }
             }
+            PHD(9);
             if (K > 1) {                                                        // Phi_upweight! (src/misc.jl:50-59)
 #pragma unroll
                 for (int u = 0; u < PPL; ++u) {
@@ -1628,6 +1669,7 @@ struct Sweep2 {
             // same number the sums are exact (P ones): ESS == P, no exps
             double mx = red[0], mn = red[4];
             for (int w_ = 1; w_ < T / 64; ++w_) { mx = (red[w_] > mx) ? red[w_] : mx; mn = (red[4 + w_] < mn) ? red[4 + w_] : mn; }
+            PHD(10);
             const bool lw_flat = mx == mn;
             if (!lw_flat) {
                 double sa = 0.0, sq = 0.0;
@@ -1705,6 +1747,7 @@ struct Sweep2 {
                 if (failed == 1) PM2_G(int, a.err)[chain] = -4;                            // PMDI_E_POOL
                 else if (a.requeue) {
                     PM2_G(int, a.requeue)[chain] = 1;                                      // sweep again with the general kernel
+                    if (a.handed) PM2_G(int, a.handed)[chain] = a.sweep_no;
                     if (a.requeue_total) { pm2_atomic_add((u64 *)a.requeue_total + 3, (u64)1); pm2_atomic_add((u64 *)a.requeue_total + (failed - 2), (u64)1); }
                 }
                 else PM2_G(int, a.err)[chain] = PMDI_S2_REQUEUE;                           // (no requeue list: report it)

@@ -40,10 +40,12 @@ for it in range(burn + iters):
     last_gb = gb
 if os.environ.get("PMDI_PHASE_TIMERS"):
     names = ["prefix", "cluster", "wait1", "particle", "wait2", "ess+book", "wait3", "follow", "resample", "finish"]
+    if os.environ.get("PM2_DETAIL"):      # a library built with -DPM2_DETAIL_TIMERS (PMDI_LIB_PATH)
+        names = ["needset", "terms", "sums", "uncached", "cdf", "rows", "draws", "chosen+hist", "census", "phi+max", "ess", "lists", "book", "stats", None, "other"]
     cs = sw.chain_costs()
     for c in np.argsort(cs)[[0, C // 4, C // 2, 3 * C // 4, C - 1]]:
         ph = sw.phase_timers(int(c)).astype(np.float64)
         tot = ph[14] if ph[14] > 0 else ph[:10].sum()
         nres = g.results()["stats"][c, 1]
         print(f"chain {c}: {tot / 1e6:8.1f} Mcycles, {nres} resamples ({ph[8] / max(nres, 1) / 1e3:.1f} kcycles each); per observation "
-              + " ".join(f"{nm} {ph[i] / n_s / 1e3:.2f}k" for i, nm in enumerate(names)))
+              + " ".join(f"{nm} {ph[i] / n_s / 1e3:.2f}k" for i, nm in enumerate(names) if nm))
