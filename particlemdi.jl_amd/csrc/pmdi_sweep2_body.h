@@ -119,11 +119,10 @@ typedef unsigned char u8;
 
 constexpr int T = 256;          // threads of the workgroup (4 waves)
 constexpr int NS = 8;           // cluster cache slots per dataset (registers of the owner wave)
-constexpr int XR = 2;           // extra (uncached) clusters evaluated per round
+constexpr int XR = 1;           // extra (uncached) clusters evaluated per round
 constexpr int XCAP = 24;        // uncached reachable clusters per step at most (beyond: requeue)
 constexpr int NR = NS + XR;     // term rows per dataset
-constexpr int CLS = 4;          // particle classes per dataset at most (beyond: requeue)
-constexpr int NDCAP = 256;      // distinct chosen clusters per step at most (beyond: requeue)
+constexpr int CLS = 8;          // particle classes per dataset at most (beyond: requeue)
 constexpr int KMAX2 = 4;        // datasets (one owner wave each)
 constexpr int NONE8 = 0xFF;
 constexpr unsigned INFU = 0xFFFFFFFFu;
@@ -173,7 +172,7 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     L.slot_id = take(NS * 4); L.slot_cn = take(NS * 4); L.slot_g = take(NS * 8);
     L.clsval = take(CLS * 4); L.clslead = take(CLS * 4); L.leadcol = take(CLS * 4);
     L.minp = take(CLS * N * 4); L.nidv = take(CLS * N * 4); L.knew = take(CLS * N); L.itemj = take(CLS * N);
-    L.clist = take(NDCAP * 2); L.klist = take(CLS * N * 4); L.kval = take(CLS * N * 4); L.krep = take(CLS * N * 4);
+    L.clist = take(idcap * 2); L.klist = take(CLS * N * 2); L.kval = take(CLS * N * 4); L.krep = take(CLS * N);
     L.bmc = take((P / 64 + 1) * 8); L.bmf = take((P / 64 + 1) * 8);
     L.cbm = take(((idcap + 63) / 64) * 8); L.kbm = take(((CLS * N + 63) / 64) * 8);
     L.xid = take(XCAP * 4);
@@ -200,6 +199,7 @@ struct Arena {   // the chain's arrays of one dataset in global memory (what exc
     PM2_DEV int *firstp() const { return (int *)(b + d->o_firstc); }
     PM2_DEV int *tgt() const { return (int *)(b + d->o_lp); }
     PM2_DEV double *sb() const { return (double *)(b + d->o_sb); }
+    PM2_DEV int *dl() const { return (int *)(b + d->o_dl); }
     PM2_DEV u8 *sstar() const { return (u8 *)(b + d->o_sstar); }
 };
 
@@ -376,7 +376,7 @@ struct Sweep2 {
     RegArr<double, PPL> lw;
     static constexpr int NCP = (PPL + 1) / 2;
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
-    unsigned cslp;              // class slot of the lane's particles per dataset, 2 bits each: bit offset 2 * (k * PPL + u)
+    u64 cslp;                   // class slot of the lane's particles per dataset, 3 bits each: bit offset 3 * (k * PPL + u)
     RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
 #ifdef PM2_DETAIL_TIMERS
     long long phd_last;
@@ -426,8 +426,8 @@ struct Sweep2 {
     {
         lw.set(u, x);
     }
-    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp >> (2 * (k * PPL + u))) & 3u); }
-    PM2_DEV void csl_put(int k, int u, int r) { const int sh = 2 * (k * PPL + u); cslp = (cslp & ~(3u << sh)) | ((unsigned)r << sh); }
+    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp >> (3 * (k * PPL + u))) & 7ull); }
+    PM2_DEV void csl_put(int k, int u, int r) { const int sh = 3 * (k * PPL + u); cslp = (cslp & ~(7ull << sh)) | ((u64)r << sh); }
     PM2_DEV DV view(int k) const
     {
         DV v;
@@ -803,7 +803,9 @@ struct Sweep2 {
         const u8 *fl = flk(k);
         const int maxid = PM2_UNI(dsc[DS_MAXID]), ncol = PM2_UNI(dsc[DS_NCOL]), ncls = PM2_UNI(dsc[DS_NCLS]);
         u16 *clist = lds<u16>(v.base + L.clist);
-        int *klist = lds<int>(v.base + L.klist), *kval = lds<int>(v.base + L.kval), *krep = lds<int>(v.base + L.krep);
+        u16 *klist = lds<u16>(v.base + L.klist);
+        int *kval = lds<int>(v.base + L.kval);
+        u8 *krep = lds<u8>(v.base + L.krep);
         PHD(11);
         // the chosen clusters and the touched keys, from the bitmaps the particle phase marked, as dense lists
         int nd = 0, nk = 0, nd_low = 0;
@@ -816,19 +818,18 @@ struct Sweep2 {
                 nd += pm2_popc64(bits);
             }
             const int ndx = PM2_UNI(dsc[DS_NDX]);
-            if (nd + ndx > NDCAP) { if (lane == 0) sc()[SC_FAIL] = 3; return false; }          // too many distinct chosen clusters
-            nd_low = nd;                      // (entries nd_low.. are the overflow list: ids beyond the LDS tables, filled from the top)
+            nd_low = nd;                      // (entries nd_low.. are the overflow list in the arena: ids beyond the LDS tables)
             nd += ndx;
             for (int w = 0; w < (CLS * N + 63) / 64; ++w) {
                 const u64 bits = kbm[w];
-                if ((bits >> lane) & 1ull) klist[nk + pm2_popc64(bits & below)] = w * 64 + lane;
+                if ((bits >> lane) & 1ull) klist[nk + pm2_popc64(bits & below)] = (u16)(w * 64 + lane);
                 nk += pm2_popc64(bits);
             }
             PM2_WAVE_BARRIER();
             for (int w = lane; w < (v.idcap + 63) / 64; w += 64) cbm[w] = 0;
             for (int w = lane; w < (CLS * N + 63) / 64; w += 64) kbm[w] = 0;
         }
-        auto chosen = [&](int e) -> int { return (int)(e < nd_low ? clist[e] : clist[NDCAP - 1 - (e - nd_low)]); };
+        auto chosen = [&](int e) -> int { if (e < nd_low) return (int)clist[e]; return PM2_G(const int, v.ar.dl())[e - nd_low]; };
         unsigned *minp = lds<unsigned>(v.base + L.minp);
         u64 *bmc = lds<u64>(v.base + L.bmc), *bmf = lds<u64>(v.base + L.bmf);
         // the statistics of the first chosen cluster (the only one in most steps), on their way while the bookkeeping runs
@@ -936,7 +937,7 @@ struct Sweep2 {
                 const unsigned mp = minp[klist[j]];
                 rep = true;
                 for (int j2 = 0; j2 < nk; ++j2) if (kval[j2] == v0 && minp[klist[j2]] < mp) rep = false;
-                krep[j] = rep ? 1 : 0;
+                krep[j] = rep ? (u8)1 : (u8)0;
             }
             nrep += pm2_popc64(PM2_BALLOT(rep));
         }
@@ -1106,7 +1107,7 @@ struct Sweep2 {
             } else {
                 const int old = pm2_atomic_min(v.ar.firstp() + c, p);       // (idle value INF: the first toucher lists the cluster)
                 pm2_atomic_add(v.ar.ncop() + c, cnt);
-                if (old == 0x7fffffff) { const int idx = pm2_atomic_add(&dsc[DS_NDX], 1); if (idx < NDCAP) lds<u16>(v.base + L.clist)[NDCAP - 1 - idx] = (u16)c; }
+                if (old == 0x7fffffff) { const int idx = pm2_atomic_add(&dsc[DS_NDX], 1); PM2_G(int, v.ar.dl())[idx] = c; }
             }
             // (class, label) key: first particle, with its column
             const int key = r * N + ns;
@@ -1751,7 +1752,9 @@ struct Sweep2 {
                     if (a.requeue_total) { pm2_atomic_add((u64 *)a.requeue_total + 3, (u64)1); pm2_atomic_add((u64 *)a.requeue_total + (failed - 2), (u64)1); }
                 }
                 else PM2_G(int, a.err)[chain] = PMDI_S2_REQUEUE;                           // (no requeue list: report it)
-                PM2_G(long long, a.stats)[(size_t)chain * 8 + 7] = failed;                // (why: 2 reachable clusters, 3 chosen clusters, 4 classes)
+                // (the general kernel may sweep the chain with K cooperating workgroups that ADD their counters)
+                for (int e = 0; e < 8; ++e) PM2_G(long long, a.stats)[(size_t)chain * 8 + e] = 0;
+                PM2_G(long long, a.stats)[(size_t)chain * 8 + 7] = (a.requeue && failed != 1) ? 0 : failed;
                 PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
             }
             if (failed == 1) {
