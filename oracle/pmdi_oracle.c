@@ -27,7 +27,6 @@
 #include "pmdi_oracle.h"
 
 #include <math.h>
-#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -495,11 +494,6 @@ void pmdi_oracle_draw_partstar(const double *logweight, int64_t P, double u01,
     if (j >= P) j = P - 1;
     /* partstar is sorted; put 1 in slot j and re-sort = drop element j,
      * shift the ones before it up by one, 1 in front */
-    if (getenv("ORACLE_DEBUG")) {
-        fprintf(stderr, "O resample last %.17g u0 %.17g j %lld raw:", last, u01 / (double)P, (long long)j);
-        for (int64_t m = 0; m < P; ++m) fprintf(stderr, " %lld", (long long)partstar[m] - 1);
-        fprintf(stderr, "\n");
-    }
     for (int64_t m = j; m > 0; --m) partstar[m] = partstar[m - 1];
     partstar[0] = 1;
     free(pprob);
@@ -684,15 +678,6 @@ int pmdi_oracle_sweep(pmdi_oracle *h, int64_t iter, const int64_t *s_in,
                     for (int nn = 0; nn < N; ++nn) dict[nn] = fprob[nn];
                     h->fprob_done[id] = 1;
                     st.sum_classes += 1;
-                    if (getenv("ORACLE_DEBUG") && pos - (n1 - 1) <= atoi(getenv("ORACLE_DEBUG"))) {
-                        fprintf(stderr, "O pos %lld k %d class %lld leader %d inc %.17g ids:", (long long)pos, k, (long long)id, p, logprob_inc);
-                        for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %lld", (long long)part_p[nn]);
-                        fprintf(stderr, " lp:");
-                        for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", logprob[part_p[nn]]);
-                        fprintf(stderr, " cdf:");
-                        for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", dict[nn]);
-                        fprintf(stderr, "\n");
-                    }
                 }
                 int64_t new_s;
                 if (p != 0) {                         /* :251-260 */

@@ -336,12 +336,6 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (settled chains): %s", hipGetErrorString(e));
             SweepArgs ar = al;
             ar.group_flag = nullptr; ar.requeue_only = 1;
-            // ... in the latency form when the model has several datasets (K cooperating workgroups per chain: the few chains
-            // that come back are the tail of the sweep, and that form sweeps a chain about twice as fast)
-            if (h->cfg.K > 1 && h->d_xcnt.p) {
-                ar.ksplit = 1;
-                HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, h->stream2));
-            }
             e = launch_one(h, ar, (SweepArgs *)h->d_args5.p, C, 256, h->stream2);
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (chains given back by the settled-chain kernel): %s", hipGetErrorString(e));
         } else {
@@ -680,7 +674,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 }
         }
     }
-    if ((h->ksplit || (h->s2_ok && K > 1 && (long long)K * n < (1LL << 27))) && ((rc = h->d_xcnt.ensure((size_t)C * 32 * 4)) || (rc = h->d_xinc.ensure((size_t)C * 2 * K * P * 8)) ||
+    if (h->ksplit && ((rc = h->d_xcnt.ensure((size_t)C * 32 * 4)) || (rc = h->d_xinc.ensure((size_t)C * 2 * K * P * 8)) ||
                       (rc = h->d_xlab.ensure((size_t)C * 2 * K * P * 4)) || (rc = h->d_xhdr.ensure((size_t)C * 2 * K * 16))))
         return bail(rc);
     if (cfg->q2_mode == 1 &&       // ancestor log of the resampling events: up to one per swept observation
