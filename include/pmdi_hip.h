@@ -323,8 +323,8 @@ int pmdi_work_counters(pmdi_handle *h, int64_t *out);
 /* 1 when the handle's light chains (few live clusters per step: what a chain looks like after its first iterations) are swept by
  * the settled-chain kernel (csrc/pmdi_sweep2.hip: all-Gaussian configurations, K <= 4, N <= 64, D <= 64, P in {256, 512, 1024},
  * default quirk modes, one workgroup per chain; PMDI_SETTLED=0 switches it off), else 0.  given_back4 (optional, 4 Int64): chains
- * that kernel has handed back to the general kernel so far because a step outgrew its tables -- [0] more clusters reachable
- * from the class leaders than its cluster cache and LDS table hold (32), [1] unused (0), [2] more than 8 particle classes, [3] in total.  A handed-back
+ * that kernel has handed back to the general kernel so far because a step outgrew its tables -- [0] unused (0:
+ * any number of reachable clusters is evaluated in place), [1] of [2]: more than 16 particle classes, [2] more than 8 particle classes, [3] in total.  A handed-back
  * chain is swept again from the start of the same sweep by the general kernel: results never depend on which kernel ran. */
 int pmdi_settled_kernel(pmdi_handle *h, int64_t *given_back4);
 

@@ -284,6 +284,7 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
     const int C = h->cfg.n_chains;
     hipError_t e;
     a.err_keep = h->err_keep;
+    a.sweep_no = ++h->sweep_no;        // (counts the sweeps of this handle: how long ago was a chain given back?)
     if (h->ksplit) {       // arrival counters of the hand-offs; the K workgroups of a chain ADD their counters into stats
         HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, st));
         HIP_TRY(hipMemsetAsync(a.stats, 0, (size_t)C * 64, st));
@@ -605,7 +606,8 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 if (idcap > 4096) idcap = 4096;
                 pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
                 while (h->s2.total > 80 * 1024 && (cols_l > 16 || idcap > 64)) {
-                    if (cols_l > 16) cols_l /= 2; else idcap /= 2;
+                    // (a settled chain holds 6-40 columns and ids below ~40 at the 99th percentile of its steps: the id tables go first)
+                    if (idcap > 96) idcap -= 16; else if (cols_l > 32) cols_l -= 8; else if (idcap > 64) idcap -= 16; else cols_l -= 8;
                     pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
                 }
                 ok = h->s2.total <= 80 * 1024;

@@ -16,8 +16,8 @@
 //     leaf scans, the exact u += 1/P sequence per lane, slot counts by direct comparison, the gather through LDS, columns and
 //     ids compacted per column / per id.
 //
-// A chain that does not fit (more particle classes than CLS, more distinct chosen clusters than NDCAP, more reachable clusters
-// than the row table) stops with err = PMDI_S2_REQUEUE and is swept again, from the start, by pmdi_sweep.hip in the same call.
+// A chain that does not fit (more particle classes than CLS in a step) stops with err = PMDI_S2_REQUEUE and is swept again, from
+// the start, by pmdi_sweep.hip in the same call.
 //
 // Everything here is written against a small lane API (PM2_* macros) so that tests/emu/ can run the same source on the CPU in a
 // lock-step workgroup emulator (test infrastructure; the product build is hipcc for gfx950 only).
@@ -41,6 +41,7 @@
 #define PM2_LDS_BARRIER() wavesim::block_barrier(__LINE__)
 #define PM2_UNI(x) (x)
 #define PM2_CLOCK() (0ll)
+#define PM2_WALLCLOCK() (0ll)
 #define PM2_G(T, p) ((T *)(p))
 #define PM2_CONST
 #define PM2_LAUNDER(ptr_, T) do { } while (0)
@@ -65,6 +66,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
 #define PM2_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PM2_UNI(x) __builtin_amdgcn_readfirstlane(x)
 #define PM2_CLOCK() ((long long)clock64())
+#define PM2_WALLCLOCK() ((long long)wall_clock64())      // constant-rate counter shared by the whole device (100 MHz)
 // arena / argument pointers are global memory: PM2_G types them so (global_* instead of flat_* instructions); what holds one is
 // declared `auto` (a generic pointer variable would drop the address space again).  The host pass of a HIP compile only parses the
 // device code: no address spaces there.
@@ -107,10 +109,32 @@ namespace pmdi_s2 {
 // sixteen slots of the phase-timer record then hold: 0 need set, 1 terms, 2 ordered sums, 3 uncached clusters, 4 CDF, 5 class rows,
 // 6 random draws, 7 chosen clusters + history, 8 census, 9 Phi + maximum, 10 ESS sums, 11 lists of the bookkeeping phase, 12 its
 // fast path / clone, class and column work, 13 statistics, 15 clean-up, 14 the whole sweep
+// -DPM2_DETAIL_TIMERS=2: the resampling event instead -- 0 weights + uniforms, 1 pairwise cumsum, 2 u table, 3 slot counts, 4 slot
+// search, 5 ancestors, 6 per dataset: scatter + gather, 7 particles per column + class leaders, 8 column ranks, 9 id occupancy,
+// 10 id ranks, 11 counts move, 12 statistics move, 13 cache + column compaction + classes; 15 everything outside resampling
 #ifdef PM2_DETAIL_TIMERS
-#define PHD(i_) do { if (ap->phase && tid == 0) { const long long t_ = PM2_CLOCK(); lds<long long>(L.ph)[phd_cur] += t_ - phd_last; phd_last = t_; phd_cur = (i_); } } while (0)
+#define PHX(i_) do { if (ap->phase && tid == 0) { const long long t_ = PM2_CLOCK(); lds<long long>(L.ph)[phd_cur] += t_ - phd_last; phd_last = t_; phd_cur = (i_); } } while (0)
+// -DPM2_DETAIL_TIMERS=3: the bookkeeping phase of dataset 0 -- 0 lists, 1 fast-path test, 2 clone-or-in-place, 3 class ids, 4 class
+// representatives, 5 column splits, 6 class list, 7 statistics of the chosen clusters, 8 clean-up + counters, 9 the barrier after
+#if PM2_DETAIL_TIMERS == 2
+#define PHD(i_) PHX(15)
+#define PHR(i_) PHX(i_)
+#define PHC(i_) do { } while (0)
+#elif PM2_DETAIL_TIMERS == 3
+// (every owner wave adds its own times: the slots hold sums over the K datasets)
+#define PHXW(i_) do { if (ap->phase && lane == 0 && wave < K) { const long long t_ = PM2_CLOCK(); pm2_atomic_add((u64 *)(lds<long long>(L.ph) + phd_cur), (u64)(t_ - phd_last)); phd_last = t_; phd_cur = (i_); } } while (0)
+#define PHD(i_) PHXW(15)
+#define PHR(i_) do { } while (0)
+#define PHC(i_) PHXW(i_)
+#else
+#define PHD(i_) PHX(i_)
+#define PHR(i_) do { } while (0)
+#define PHC(i_) do { } while (0)
+#endif
 #else
 #define PHD(i_) do { } while (0)
+#define PHR(i_) do { } while (0)
+#define PHC(i_) do { } while (0)
 #endif
 
 typedef unsigned long long u64;
@@ -119,10 +143,15 @@ typedef unsigned char u8;
 
 constexpr int T = 256;          // threads of the workgroup (4 waves)
 constexpr int NS = 8;           // cluster cache slots per dataset (registers of the owner wave)
-constexpr int XR = 1;           // extra (uncached) clusters evaluated per round
-constexpr int XCAP = 24;        // uncached reachable clusters per step at most (beyond: requeue)
-constexpr int NR = NS + XR;     // term rows per dataset
-constexpr int CLS = 8;          // particle classes per dataset at most (beyond: requeue)
+constexpr int XR = 4;           // uncached clusters evaluated per round (their two term rows each borrow the cached clusters' tb rows)
+#ifndef PM2_XCAP
+#define PM2_XCAP 24
+#endif
+constexpr int XCAP = PM2_XCAP;  // uncached reachable clusters whose list entry and log-predictive live in LDS (the rest: arena)
+constexpr int NR = NS;          // term rows per dataset
+constexpr int CLS = 16;         // particle classes per dataset at most (beyond: requeue)
+constexpr int CSB = 4;          // bits of a class slot in the per-lane register word
+constexpr int RI_CLSMIN = 64, RI_NEWSLOT = 80, RI_CLSVAL = 96;      // resampling: per-class scratch, int offsets into the reduction area
 constexpr int KMAX2 = 4;        // datasets (one owner wave each)
 constexpr int NONE8 = 0xFF;
 constexpr unsigned INFU = 0xFFFFFFFFu;
@@ -146,12 +175,17 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     L.stat = take(8 * 8);
     L.wk = take(KMAX2 * 8 * 8);
     L.ph = take(16 * 8);
-    L.leaf_i1 = take(64 * 4); L.leaf_n = take(64 * 4); L.leaf_tot = take(64 * 8); L.leaf_carry = take(64 * 8); L.leaf_prog = take(256);
+    L.leaf_i1 = 0; L.leaf_n = 0; L.leaf_prog = 0;
+    L.leaf_tot = take(64 * 8); L.leaf_carry = take(64 * 8);      // block totals and the level totals of the cumsum's recursion tree
     L.xfl = take(KMAX2 * 64);                                   // feature flags per dataset (bytes)
     // transient region
     L.tr_tb = 0;
-    L.tr_cdf = NR * Dp * 8 < 128 * 8 ? 128 * 8 : NR * Dp * 8;      // (the tb rows also lend their space to the CDF stage's exchange area and to the prefix's label table)
-    L.tr_stride = (L.tr_cdf + CLS * (N + 2) * 8 + 15) & ~15;
+    // the tb rows are dead once the ordered sums are done: their first 1 KiB is the CDF stage's exchange area (and the prefix's label
+    // table), the class CDF rows (alive until the particle phase ends) start right behind it
+    L.tr_cdf = 128 * 8;
+    L.tr_stride = L.tr_cdf + CLS * (N + 2) * 8;
+    if (L.tr_stride < NR * Dp * 8) L.tr_stride = NR * Dp * 8;
+    L.tr_stride = (L.tr_stride + 15) & ~15;
     // resampling scratch (aliases the transient rows): u table (P doubles; once dead: the per-dataset gather tables scol, mult,
     // cmap (u16) and scsl (u8): 7 P bytes), slot counts, raw ancestors, ancestors (u16), id histogram (i32)
     L.rs_jtab = P * 8; L.rs_raw = P * 10; L.rs_anc = P * 12; L.rs_hist = P * 14;
@@ -167,12 +201,12 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     L.cmask = take(cols_l * 8); L.wmask = take(cols_l * 8); L.cbi = take(cols_l * 4);
     L.counts = take(idcap * 4); L.cn = take(idcap * 4); L.ncop = take(idcap * 4); L.firstp = take(idcap * 4); L.tgt = take(idcap * 4);
     L.slotmap = take(idcap);
-    L.ta = take(NS * Dp * 8); L.tax = take(XR * Dp * 8);
+    L.ta = take(NS * Dp * 8); L.tax = L.ta;
     L.lp = take((NS + XCAP) * 8);
     L.slot_id = take(NS * 4); L.slot_cn = take(NS * 4); L.slot_g = take(NS * 8);
     L.clsval = take(CLS * 4); L.clslead = take(CLS * 4); L.leadcol = take(CLS * 4);
-    L.minp = take(CLS * N * 4); L.nidv = take(CLS * N * 4); L.knew = take(CLS * N); L.itemj = take(CLS * N);
-    L.clist = take(idcap * 2); L.klist = take(CLS * N * 2); L.kval = take(CLS * N * 4); L.krep = take(CLS * N);
+    L.minp = take(CLS * N * 4); L.nidv = take(CLS * N * 2); L.knew = take(CLS * N); L.itemj = take(CLS * N * 2);
+    L.clist = take(idcap * 2); L.klist = take(CLS * N * 2); L.kval = take(CLS * N * 2); L.krep = take(CLS * N);
     L.bmc = take((P / 64 + 1) * 8); L.bmf = take((P / 64 + 1) * 8);
     L.cbm = take(((idcap + 63) / 64) * 8); L.kbm = take(((CLS * N + 63) / 64) * 8);
     L.xid = take(XCAP * 4);
@@ -201,6 +235,8 @@ struct Arena {   // the chain's arrays of one dataset in global memory (what exc
     PM2_DEV double *sb() const { return (double *)(b + d->o_sb); }
     PM2_DEV int *dl() const { return (int *)(b + d->o_dl); }
     PM2_DEV u8 *sstar() const { return (u8 *)(b + d->o_sstar); }
+    PM2_DEV double *lpx() const { return (double *)(b + d->o_cdf); }                      // log-predictives of the uncached clusters beyond XCAP
+    PM2_DEV int *xidx() const { return (int *)(b + d->o_cdf) + 2 * CLS * 64; }           // ... and their ids (CLS * N <= CLS * 64 entries each)
 };
 
 struct DV {      // view of one dataset: LDS block + arena
@@ -239,10 +275,15 @@ struct DV {      // view of one dataset: LDS block + arena
     PM2_DEV int firstp_min(int id, int x) const { if (id < idcap) return pm2_atomic_min(lds<int>(base + lay->firstp) + id, x); return pm2_atomic_min(ar.firstp() + id, x); }
     PM2_DEV int slot_of(int id) const { return id < idcap ? (int)lds<u8>(base + lay->slotmap)[id] : NONE8; }
     PM2_DEV void slot_set(int id, int s) const { if (id < idcap) lds<u8>(base + lay->slotmap)[id] = (u8)s; }
-    PM2_DEV double *ta_row(int j) const { return j < NS ? lds<double>(base + lay->ta) + j * Dp : lds<double>(base + lay->tax) + (j - NS) * Dp; }
+    PM2_DEV double *ta_row(int j) const { return lds<double>(base + lay->ta) + j * Dp; }
     PM2_DEV double *tb_row(int j) const { return lds<double>(trb + lay->tr_tb) + j * Dp; }
     PM2_DEV double *cdf_row(int r) const { return lds<double>(trb + lay->tr_cdf) + r * (N + 2); }
     PM2_DEV double *lp() const { return lds<double>(base + lay->lp); }
+    // row j of the step's log-predictives: cache slots [0, NS), then the uncached clusters in the order they were listed
+    PM2_DEV double lp_get(int j) const { if (j < NS + XCAP) return lp()[j]; return PM2_G(const double, ar.lpx())[j - NS - XCAP]; }
+    PM2_DEV void lp_set(int j, double x) const { if (j < NS + XCAP) lp()[j] = x; else PM2_G(double, ar.lpx())[j - NS - XCAP] = x; }
+    PM2_DEV int xid_get(int e) const { if (e < XCAP) return lds<int>(base + lay->xid)[e]; return PM2_G(const int, ar.xidx())[e - XCAP]; }
+    PM2_DEV void xid_set(int e, int id) const { if (e < XCAP) lds<int>(base + lay->xid)[e] = id; else PM2_G(int, ar.xidx())[e - XCAP] = id; }
 };
 
 PM2_DEV double shfl_d(double v, int src)
@@ -376,7 +417,8 @@ struct Sweep2 {
     RegArr<double, PPL> lw;
     static constexpr int NCP = (PPL + 1) / 2;
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
-    u64 cslp;                   // class slot of the lane's particles per dataset, 3 bits each: bit offset 3 * (k * PPL + u)
+    u64 cslp;                   // class slot of the lane's particles per dataset, CSB bits each: bit offset CSB * (k * PPL + u)
+    static_assert(CSB * K * PPL <= 64 && (1 << CSB) >= CLS, "class slots of a lane's particles must fit one 64-bit word");
     RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
 #ifdef PM2_DETAIL_TIMERS
     long long phd_last;
@@ -426,8 +468,8 @@ struct Sweep2 {
     {
         lw.set(u, x);
     }
-    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp >> (3 * (k * PPL + u))) & 7ull); }
-    PM2_DEV void csl_put(int k, int u, int r) { const int sh = 3 * (k * PPL + u); cslp = (cslp & ~(7ull << sh)) | ((u64)r << sh); }
+    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp >> (CSB * (k * PPL + u))) & (u64)((1 << CSB) - 1)); }
+    PM2_DEV void csl_put(int k, int u, int r) { const int sh = CSB * (k * PPL + u); cslp = (cslp & ~((u64)((1 << CSB) - 1) << sh)) | ((u64)r << sh); }
     PM2_DEV DV view(int k) const
     {
         DV v;
@@ -563,9 +605,8 @@ struct Sweep2 {
         const int ncls = PM2_UNI(dsc[DS_NCLS]);
         const u8 *fl = flk(k);
         const bool on = lane < D && fl[lane];
-        u8 *itemj = lds<u8>(v.base + L.itemj);
+        u16 *itemj = lds<u16>(v.base + L.itemj);
         int *slot_id = lds<int>(v.base + L.slot_id);
-        int *xid = lds<int>(v.base + L.xid);
         PHD(0);
         if (lane == 0 && pend_slot >= 0) { lds<double>(v.base + L.slot_g)[pend_slot] = (double)dsc[DS_NFLAG] * pend_g; pend_slot = -1; }
         // -- A1: the clusters the class leaders' columns hold; their cache slots (stable while a cluster stays reachable).  Skipped
@@ -578,33 +619,37 @@ struct Sweep2 {
 #endif
         if (PM2_UNI(dsc[DS_DIRTY]) == 0) { needmask = (unsigned)PM2_UNI(dsc[DS_NEEDMASK]); nx = PM2_UNI(dsc[DS_NX]); }
         else {
-        int item_id[CLS];
-        int nid_pref[CLS];
+        // the leaders' columns, four classes at a time: cache slots in use; new_id of the (class, label) keys, fetched now (four loads in
+        // flight) and needed after the draw (:266)
+        for (int r0 = 0; r0 < ncls; r0 += 4) {
+            int nid_pref[4];
 #pragma unroll
-        for (int r = 0; r < CLS; ++r) {
-            item_id[r] = 0; nid_pref[r] = 0;
-            if (r < ncls) {
-                const int lc = lds<int>(v.base + L.leadcol)[r];
+            for (int j = 0; j < 4; ++j) {
+                const int r = r0 + j;
+                nid_pref[j] = 0;
+                if (r < ncls) {
+                    const int lc = lds<int>(v.base + L.leadcol)[r];
 #ifdef PM2_EMU
-                if (lc < 0 || lc >= P) { fprintf(stderr, "phase_a: pos %lld k %d r %d ncls %d leadcol %d (lane %d)\n", pos, k, r, ncls, lc, lane); abort(); }
+                    if (lc < 0 || lc >= P) { fprintf(stderr, "phase_a: pos %lld k %d r %d ncls %d leadcol %d (lane %d)\n", pos, k, r, ncls, lc, lane); abort(); }
 #endif
-                const int id = (lane < N) ? v.tab_get(lc, lane) : 0;
-                item_id[r] = id;
-                const int s = (lane < N) ? v.slot_of(id) : NONE8;
-                for (int sb_ = 0; sb_ < NS; ++sb_) if (PM2_BALLOT(s == sb_)) needmask |= 1u << sb_;
-                // new_id of the (class, label) keys, fetched now and needed after the draw (:266)
-                if (lane < N && ap->q1 == 0) nid_pref[r] = PM2_G(const int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + lane];
+                    const int id = (lane < N) ? v.tab_get(lc, lane) : 0;
+                    const int s = (lane < N) ? v.slot_of(id) : NONE8;
+                    for (int sb_ = 0; sb_ < NS; ++sb_) if (PM2_BALLOT(s == sb_)) needmask |= 1u << sb_;
+                    if (lane < N && ap->q1 == 0) nid_pref[j] = PM2_G(const int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + lane];
+                }
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (r0 + j < ncls && lane < N) lds<u16>(v.base + L.nidv)[(r0 + j) * N + lane] = (u16)nid_pref[j];
         }
         int nneed_new = 0;
-#pragma unroll
-        for (int r = 0; r < CLS; ++r) {
-            if (r < ncls) {
-                const int id = item_id[r];
+#pragma nounroll
+        for (int r = 0; r < ncls; ++r) {
+            {
+                const int id = (lane < N) ? v.tab_get(lds<int>(v.base + L.leadcol)[r], lane) : 0;
                 int j = (lane < N) ? v.slot_of(id) : 0;
                 bool missing = lane < N && j == NONE8;
                 if (missing)                                   // an uncached cluster another class already asked for
-                    for (int e = 0; e < nx; ++e) if (xid[e] == id) { j = NS + e; missing = false; }
+                    for (int e = 0; e < nx; ++e) if (v.xid_get(e) == id) { j = NS + e; missing = false; }
                 u64 m;
                 while ((m = PM2_BALLOT(missing)) != 0) {
                     const int l0 = pm2_ffs64(m) - 1;
@@ -626,8 +671,7 @@ struct Sweep2 {
                         cache_fill(v, k, s0, sg, bt, v.cn_get(id0));
                         row = s0;
                     } else {
-                        if (nx >= XCAP) { if (lane == 0) sc()[SC_FAIL] = 2; nx = XCAP - 1; }          // too many uncached reachable clusters
-                        if (lane == 0) xid[nx] = id0;
+                        if (lane == 0) v.xid_set(nx, id0);
                         row = NS + nx;
                         nx += 1;
                     }
@@ -635,7 +679,7 @@ struct Sweep2 {
                     if (missing && id == id0) { j = row; missing = false; }
                     PM2_WAVE_BARRIER();
                 }
-                if (lane < N) { itemj[r * N + lane] = (u8)j; lds<int>(v.base + L.nidv)[r * N + lane] = nid_pref[r]; }
+                if (lane < N) itemj[r * N + lane] = (u16)j;
             }
         }
         (void)nneed_new;
@@ -645,6 +689,9 @@ struct Sweep2 {
             if (lane < NS && ((dead >> lane) & 1u)) { const int old = slot_id[lane]; if (old) { v.slot_set(old, NONE8); slot_id[lane] = 0; } }
         }
         const int nneed = __builtin_popcount(needmask) + nx;
+#ifdef PM2_EMU
+        if (lane == 0 && nx > XCAP && getenv("PM2_DEBUG_NX")) fprintf(stderr, "phase_a: pos %lld k %d: %d uncached clusters (XCAP %d)\n", pos, k, nx, XCAP);
+#endif
         if (lane == 0) { dsc[DS_NX] = nx; dsc[DS_NNEED] = nneed; dsc[DS_NEEDMASK] = (int)needmask; }
         PM2_WAVE_BARRIER();
         }
@@ -681,28 +728,39 @@ struct Sweep2 {
             lp[lane] = out;
         }
         PHD(3);
-        // uncached reachable clusters, XR per round: statistics from the pool, both terms on the fly
+        // uncached reachable clusters, XR per round: statistics from the pool, both terms on the fly into the tb rows (the cached
+        // clusters' sums are done with them): rows 2j, 2j + 1 for the j-th cluster of the round; then one lane per cluster adds
         for (int e0 = 0; e0 < nx; e0 += XR) {
             PM2_WAVE_BARRIER();
-            for (int e = e0; e < nx && e < e0 + XR; ++e) {
-                const int id = xid[e];
-                const int cnv = v.cn_get(id);
+            {
                 auto sb = PM2_G(const double, v.ar.sb());
-                if (on) {
-                    double mu, lam;
-                    pmdi_arith::gauss_ml(cnv, sb[((size_t)id * D + lane) * 2], sb[((size_t)id * D + lane) * 2 + 1], mu, lam);
-                    const double nd_ = (double)cnv, dd = x - mu;
-                    v.ta_row(NS + e - e0)[lane] = 0.5 * log(lam / (nd_ + 1.0));
-                    v.tb_row(NS + e - e0)[lane] = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
+                int idj[XR], cnj[XR];
+                double sgj[XR], btj[XR];
+#pragma unroll
+                for (int j = 0; j < XR; ++j) {
+                    idj[j] = (e0 + j < nx) ? v.xid_get(e0 + j) : 0;
+                    cnj[j] = idj[j] ? v.cn_get(idj[j]) : 0;
+                    sgj[j] = 0.0; btj[j] = 0.5;
+                    if (on && idj[j]) { sgj[j] = sb[((size_t)idj[j] * D + lane) * 2]; btj[j] = sb[((size_t)idj[j] * D + lane) * 2 + 1]; }
+                }
+#pragma unroll
+                for (int j = 0; j < XR; ++j) {
+                    if (on && idj[j]) {
+                        double mu, lam;
+                        pmdi_arith::gauss_ml(cnj[j], sgj[j], btj[j], mu, lam);
+                        const double nd_ = (double)cnj[j], dd = x - mu;
+                        v.tb_row(2 * j)[lane] = 0.5 * log(lam / (nd_ + 1.0));
+                        v.tb_row(2 * j + 1)[lane] = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
+                    }
                 }
             }
             PM2_WAVE_BARRIER();
             if (lane < XR && e0 + lane < nx) {
-                const int id = xid[e0 + lane];
-                const double *ta = v.ta_row(NS + lane), *tb = v.tb_row(NS + lane);
+                const int id = v.xid_get(e0 + lane);
+                const double *ta = v.tb_row(2 * lane), *tb = v.tb_row(2 * lane + 1);
                 double out = (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[v.cn_get(id)];
                 for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
-                lp[NS + e0 + lane] = out;
+                v.lp_set(NS + e0 + lane, out);
             }
         }
         PM2_WAVE_BARRIER();
@@ -719,7 +777,7 @@ struct Sweep2 {
                 const int r = r0 + g;
                 const bool valid = (g < G) && (r < ncls);
                 double val = 0.0;
-                if (valid) val = lp[itemj[r * N + nn]];
+                if (valid) val = v.lp_get(itemj[r * N + nn]);
                 wv[lane] = val;
                 PM2_WAVE_BARRIER();
                 double m = val;
@@ -780,7 +838,7 @@ struct Sweep2 {
                 fprintf(stderr, "E pos %lld k %d class %d leader %d inc %.17g ids:", pos, k, lds<int>(v.base + L.clsval)[r], lds<int>(v.base + L.clslead)[r], v.cdf_row(r)[N]);
                 for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %d", v.tab_get(lds<int>(v.base + L.leadcol)[r], nn));
                 fprintf(stderr, " lp:");
-                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", lp[itemj[r * N + nn]]);
+                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", v.lp_get(itemj[r * N + nn]));
                 fprintf(stderr, " cdf:");
                 for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", v.cdf_row(r)[nn]);
                 fprintf(stderr, "\n");
@@ -804,9 +862,10 @@ struct Sweep2 {
         const int maxid = PM2_UNI(dsc[DS_MAXID]), ncol = PM2_UNI(dsc[DS_NCOL]), ncls = PM2_UNI(dsc[DS_NCLS]);
         u16 *clist = lds<u16>(v.base + L.clist);
         u16 *klist = lds<u16>(v.base + L.klist);
-        int *kval = lds<int>(v.base + L.kval);
+        u16 *kval = lds<u16>(v.base + L.kval);          // (class ids are at most P)
         u8 *krep = lds<u8>(v.base + L.krep);
         PHD(11);
+        PHC(0);
         // the chosen clusters and the touched keys, from the bitmaps the particle phase marked, as dense lists
         int nd = 0, nk = 0, nd_low = 0;
         {
@@ -840,12 +899,13 @@ struct Sweep2 {
             pf_sg = sb0[((size_t)c0 * D + lane) * 2]; pf_bt = sb0[((size_t)c0 * D + lane) * 2 + 1];
         }
         PHD(12);
+        PHC(1);
         // -- C0: the step of a settled chain, most of the time: one class, every particle drew the same label and the same cluster,
         // all references of that cluster were chosen (so it is updated in place, :286-290), the (class, label) key is known and keeps
         // the class its value: no clone, no new class, no column changes -- the statistics, the cache and the idle state of the census
         if (nd == 1 && nk == 1 && ncls == 1 && ap->q1 == 0) {
             const int c = chosen(0), key = klist[0];
-            const int v0 = lds<int>(v.base + L.nidv)[key];
+            const int v0 = lds<u16>(v.base + L.nidv)[key];
             if (v.ncop_get(c) == v.counts_get(c) && v0 > 0 && v0 == lds<int>(v.base + L.clsval)[0]) {
                 const int nnew = v.cn_get(c) + 1;
                 const int s0 = v.slot_of(c);
@@ -875,6 +935,7 @@ struct Sweep2 {
             }
         }
         // -- C1: clone or in place (:286-299): a chosen cluster all of whose references were chosen is updated in place
+        PHC(2);
         for (int e0 = 0; e0 < nd; e0 += 64) {
             const int e = e0 + lane;
             if (e < nd) {
@@ -902,11 +963,12 @@ struct Sweep2 {
         }
         // -- C2: class ids of the next step (:266-272): a (class, label) key met for the first time in this Gibbs iteration gets
         // the next id in particle order (curr_id restarts at 0 every step: Q1), others reuse the id stored under the key
+        PHC(3);
         for (int j0 = 0; j0 < nk; j0 += 64) {
             const int j = j0 + lane;
             if (j < nk) {
                 const int key = klist[j];
-                const int v0 = (ap->q1 == 1) ? 0 : lds<int>(v.base + L.nidv)[key];
+                const int v0 = (ap->q1 == 1) ? 0 : (int)lds<u16>(v.base + L.nidv)[key];
                 if (v0 <= 0) { const int pf = (int)(minp[key] >> 16); pm2_atomic_or(&bmf[pf >> 6], 1ull << (pf & 63)); }
             }
         }
@@ -916,18 +978,19 @@ struct Sweep2 {
             if (j < nk) {
                 const int key = klist[j];
                 const int r = key / N, ns = key - r * N;
-                int v0 = (ap->q1 == 1) ? 0 : lds<int>(v.base + L.nidv)[key];
+                int v0 = (ap->q1 == 1) ? 0 : (int)lds<u16>(v.base + L.nidv)[key];
                 if (v0 <= 0) {
                     v0 = 1 + popc_below64(bmf, (int)(minp[key] >> 16));            // curr_id += 1 (:267-269)
                     if (ap->q1 == 0) PM2_G(int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + ns] = v0;
                     dsc[DS_CHANGED] = 1;                                            // (new_id changed under a key of this class)
                 }
                 if (v0 != lds<int>(v.base + L.clsval)[r]) dsc[DS_CHANGED] = 1;       // (the class does not map to itself)
-                kval[j] = v0;
+                kval[j] = (u16)v0;
             }
         }
         PM2_WAVE_BARRIER();
         // classes of the next step: one per distinct value, leader = lowest first particle, slots in leader order
+        PHC(4);
         int nrep = 0;
         for (int j0 = 0; j0 < nk; j0 += 64) {
             const int j = j0 + lane;
@@ -941,10 +1004,11 @@ struct Sweep2 {
             }
             nrep += pm2_popc64(PM2_BALLOT(rep));
         }
-        if (nrep > CLS) { if (lane == 0) sc()[SC_FAIL] = 4; return false; }           // too many particle classes
+        if (nrep > CLS) { if (lane == 0) { sc()[SC_FAIL] = 4; sc()[SC_TMP1] = nrep; } return false; }           // too many particle classes
         PM2_WAVE_BARRIER();
         // -- C3: column splits (:301-308): particles of one column that chose the same label move together; the group whose chosen
         // cluster was cloned takes a copy of the column with that entry replaced -- or the column itself when nobody stays behind
+        PHC(5);
         int ncol_new = ncol;
         if (nclone == 0) {                                   // nothing was cloned: no column changes, only the chosen-label masks go back to idle
             for (int cc = lane; cc < ncol; cc += 64) v.cmask_set(cc, 0);
@@ -996,6 +1060,7 @@ struct Sweep2 {
         }
         PM2_WAVE_BARRIER();
         // the class list of the next step and every key's class slot; the leader's column after the split
+        PHC(6);
         for (int j0 = 0; j0 < nk; j0 += 64) {
             const int j = j0 + lane;
             if (j < nk) {
@@ -1032,6 +1097,7 @@ struct Sweep2 {
         }
 #endif
         PHD(13);
+        PHC(7);
         // -- C4: deepcopy + cluster_add! of every distinct chosen cluster (:297,:300), lane = feature: (Sigma, beta) from the pool (the
         // first cluster's were fetched at the top of the phase), written to the pool; a cached cluster gets its mu, lambda and first
         // term refreshed in the owner wave's registers
@@ -1051,6 +1117,7 @@ struct Sweep2 {
             }
         }
         PHD(15);
+        PHC(8);
         // -- C5: the step's scratch back to its idle state; counters
         PM2_WAVE_BARRIER();
         for (int e0 = 0; e0 < nd; e0 += 64) {
@@ -1154,49 +1221,55 @@ struct Sweep2 {
             if (mine && lib == LPB - 1) tot[blk] = acc;
             PM2_BARRIER();
         }
-        if (tid == 0) {
-            // carries: replay the recursion over the leaf totals (program built at kernel start: op 0 = leaf, 3 = descend left,
-            // 1 = left done -> right child's carry, 2 = node done); leaf l's total sits at its LAST block
-            double *cs = lds<double>(L.red) + 64, *lt = lds<double>(L.red) + 88;      // (stacks of the replay: LDS, not scratch)
-            int sp = 0;
-            cs[0] = w[0];
-            double ret = 0.0;
-            const int nprog = sc()[SC_NPROG];
-            const u8 *prog = lds<u8>(L.leaf_prog);
-            const int *li1 = lds<int>(L.leaf_i1), *ln = lds<int>(L.leaf_n);
-            int leaf = 0;
-            for (int pc = 0; pc < nprog; ++pc) {
-                const int op = prog[pc];
-                if (op == 0) { car[leaf] = cs[sp]; ret = tot[(li1[leaf] + ln[leaf] - 1) >> 6]; ++leaf; }
-                else if (op == 3) { cs[sp + 1] = cs[sp]; ++sp; }
-                else if (op == 1) { lt[sp - 1] = ret; cs[sp] = cs[sp - 1] + ret; }
-                else { --sp; ret = lt[sp] + ret; }
+        // The carries.  Above the leaves the recursion is a fixed binary tree over the 64-element blocks (blocks 0 and 1 are the one leaf
+        // [1, 128)): a node hands its carry s to its left child and s + total(left) to its right child, and total(node) = total(left) +
+        // total(right).  Level totals first (log2(P / 64) - 1 levels, lanes = nodes), then every lane adds up its own block's path.
+        const int nb = P >> 6;
+        double *lv = car;                              // lv[off(h) + g]: total of blocks [g 2^h, (g + 1) 2^h), h >= 1; off(h) = nb - (nb >> (h - 1))
+        if (wave == 0) {
+            if (tid == 0) lds<double>(L.red)[121] = w[0];                    // c[1] = v1, the carry of everything on the left spine
+            for (int h = 1; (nb >> h) >= 2; ++h) {
+                const int cnt = nb >> h, off = nb - (nb >> (h - 1)), offp = (h >= 2) ? nb - (nb >> (h - 2)) : 0;
+                if (lane < cnt) {
+                    double val;
+                    if (h == 1) val = (lane == 0) ? tot[1] : tot[2 * lane] + tot[2 * lane + 1];
+                    else val = lv[offp + 2 * lane] + lv[offp + 2 * lane + 1];
+                    lv[off + lane] = val;
+                }
+                PM2_WAVE_BARRIER();
             }
         }
         PM2_BARRIER();
-#ifdef PM2_EMU
-        if (getenv("PM2_DEBUG") && tid == 0) {
-            fprintf(stderr, "E cumsum tot %.17g %.17g %.17g %.17g car %.17g %.17g %.17g nprog %d nleaf %d\n", tot[0], tot[1], tot[2], tot[3], car[0], car[1], car[2], sc()[SC_NPROG], sc()[SC_NLEAF]);
+        double carry = lds<double>(L.red)[121];
+        if (blk >= 2) {
+            const int j = 32 - __builtin_clz((unsigned)blk);                  // 2^(j-1) <= blk < 2^j: the right child of spine node j
+            carry = carry + lv[nb - (nb >> (j - 2))];                          // ... whose carry is v1 + total(blocks [0, 2^(j-1)))
+            for (int h = j - 2; h >= 0; --h)
+                if ((blk >> h) & 1) {
+                    const int g = (blk >> h) - 1;                              // the left sibling at level h
+                    carry = carry + (h == 0 ? tot[g] : lv[nb - (nb >> (h - 1)) + g]);
+                }
         }
-#endif
 #pragma unroll
         for (int u = 0; u < PPL; ++u) {
             const int p = tid * PPL + u;
-            const int leaf = (p < 128) ? 0 : (p >> 6) - 1;
-            c[u] = (p == 0) ? w[u] : car[leaf] + sl[u];
+            c[u] = (p == 0) ? w[u] : carry + sl[u];
         }
     }
 
     // ---- draw_partstar + gather + compact renumbering (src/misc.jl:27-47, src/pmdi.jl:318-340) ---------------------------------------
     PM2_DEV void resample(long long pos, double mx)
     {
+        PHR(0);
         double w[PPL];
 #pragma unroll
         for (int u = 0; u < PPL; ++u) w[u] = exp(lw[u] - mx);        // pprob before the cumsum (src/misc.jl:29), as calc_ESS formed it
         const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_U);
         const double usl = pmdi_arith::uniform01(seed, iter, (unsigned)pos, 0, 0, SITE_RESAMPLE_SLOT);
         double c[PPL];
+        PHR(1);
         cumsum_pairwise(w, c);
+        PHR(2);
         double *utab = lds<double>(L.tr);
         u16 *jtab = lds<u16>(L.tr + L.rs_jtab), *raw = lds<u16>(L.tr + L.rs_raw), *anc = lds<u16>(L.tr + L.rs_anc);
         double *red = lds<double>(L.red);
@@ -1224,6 +1297,7 @@ struct Sweep2 {
             for (int uu = 0; uu < PPL; ++uu) { utab[j + uu] = u; u = u + h; }
         }
         PM2_BARRIER();
+        PHR(3);
         // slots taken up to and including particle p: J_p = #{ j : pprob[p] / last >= u_j } (:32-36)
         {
             const double last = red[0];
@@ -1239,6 +1313,7 @@ struct Sweep2 {
             }
         }
         PM2_BARRIER();
+        PHR(4);
         // slot j belongs to the first particle with J_p > j
 #pragma unroll
         for (int uu = 0; uu < PPL; ++uu) {
@@ -1250,6 +1325,7 @@ struct Sweep2 {
         int js = (int)(usl * (double)P);                      // shuffle!, partstar[1] = 1, sort! (:43-45)
         if (js >= P) js = P - 1;
         PM2_BARRIER();
+        PHR(5);
 #ifdef PM2_EMU
         if (getenv("PM2_DEBUG") && tid == 0) {
             fprintf(stderr, "E resample last %.17g u0 %.17g j %d raw:", red[0], utab[0], js);
@@ -1273,6 +1349,7 @@ struct Sweep2 {
             const DV v = view(k);
             int *dsc = v.dsc();
             const int ncol_old = dsc[DS_NCOL], oldmax = dsc[DS_MAXID], ncls_old = dsc[DS_NCLS];
+            PHR(6);
             int ck[PPL], rk[PPL];                           // this dataset's column / class slot of the lane's particles
             col_get(k, ck);
 #pragma unroll
@@ -1281,7 +1358,7 @@ struct Sweep2 {
             for (int uu = 0; uu < PPL; ++uu) { const int p = tid * PPL + uu; scol[p] = (u16)ck[uu]; scsl[p] = (u8)rk[uu]; }
             for (int e = tid; e < ncol_old; e += T) mult[e] = 0;
             for (int e = tid; e <= oldmax && e < v.idcap; e += T) hist[e] = 0;
-            if (tid < CLS) lds<int>(L.red)[36 + tid] = 0x7fffffff;
+            if (tid < CLS) lds<int>(L.red)[RI_CLSMIN + tid] = 0x7fffffff;
             PM2_BARRIER();
             // particle[:, partstar, k], particle_id[partstar, k] (:322-323): a particle takes its ancestor's column index and class
 #pragma unroll
@@ -1290,6 +1367,7 @@ struct Sweep2 {
                 const int an = anc[p];
                 ck[uu] = scol[an]; rk[uu] = scsl[an];
             }
+            PHR(7);
 #pragma unroll
             for (int uu = 0; uu < PPL; ++uu) {
                 // particles per old column, aggregated over the lanes that took the same one
@@ -1310,10 +1388,11 @@ struct Sweep2 {
                 const int r = rk[uu];
                 for (int rr = 0; rr < ncls_old; ++rr) {
                     const u64 m = PM2_BALLOT(r == rr);
-                    if (m && lane == pm2_ffs64(m) - 1) pm2_atomic_min(&lds<int>(L.red)[36 + rr], tid * PPL + uu);
+                    if (m && lane == pm2_ffs64(m) - 1) pm2_atomic_min(&lds<int>(L.red)[RI_CLSMIN + rr], tid * PPL + uu);
                 }
             }
             PM2_BARRIER();
+            PHR(8);
             // new index of every column that kept a particle
             int ncol_new = 0;
             for (int b = 0; b < ncol_old; b += T) {
@@ -1328,6 +1407,7 @@ struct Sweep2 {
                 ncol_new += tot;
                 PM2_BARRIER();
             }
+            PHR(9);
             // occupancy of every old id = sum over the live columns of (particles on the column) x (entries holding the id) (:338)
             for (int idx = tid; idx < ncol_old * N; idx += T) {
                 const int cc = idx / N;
@@ -1338,6 +1418,7 @@ struct Sweep2 {
                 }
             }
             PM2_BARRIER();
+            PHR(10);
             // sort(unique(particle)) ascending -> 1..U' (:329): ranks of the live ids; the map goes to the tgt table
             int newmax = 0;
             for (int b = 0; b < oldmax; b += T) {
@@ -1355,6 +1436,7 @@ struct Sweep2 {
                 PM2_BARRIER();
             }
             // counts and cluster sizes move down with their ids, ascending (:336,:338): read a batch, barrier, write it
+            PHR(11);
             if (tid == 0) sc()[SC_TMP0] = 0;
             for (int b = 0; b < oldmax; b += T) {
                 const int id = 1 + b + tid;
@@ -1377,6 +1459,7 @@ struct Sweep2 {
                 PM2_BARRIER();
             }
             // ... and the statistics: clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending batches (:336)
+            PHR(12);
             {
                 const int D = ap->ds[k].D;
                 auto sb = PM2_G(double, v.ar.sb());
@@ -1393,6 +1476,7 @@ struct Sweep2 {
                 }
             }
             PM2_BARRIER();
+            PHR(13);
             // the cache follows the renumbering (same clusters under new ids)
             if (wave == k) {
                 int *slot_id = lds<int>(v.base + L.slot_id);
@@ -1427,32 +1511,24 @@ struct Sweep2 {
             // classes that kept a particle, in leader order; leaders' columns
             {
                 int *redi = lds<int>(L.red);
-                int newslot[CLS];
                 int nc2 = 0;
-#pragma unroll
-                for (int r = 0; r < CLS; ++r) {
-                    newslot[r] = -1;
-                    if (r < ncls_old && redi[36 + r] != 0x7fffffff) {
-                        int s = 0;
-                        for (int r2 = 0; r2 < ncls_old; ++r2) if (redi[36 + r2] < redi[36 + r]) ++s;
-                        newslot[r] = s;
-                        nc2 += 1;
-                    }
+                for (int r = 0; r < ncls_old; ++r) nc2 += (redi[RI_CLSMIN + r] != 0x7fffffff) ? 1 : 0;
+                if (tid < ncls_old) {
+                    int s = 0;
+                    const int mine = redi[RI_CLSMIN + tid];
+                    for (int r2 = 0; r2 < ncls_old; ++r2) if (redi[RI_CLSMIN + r2] < mine) ++s;
+                    redi[RI_NEWSLOT + tid] = s;                             // (a class that lost every particle is never looked up)
+                    redi[RI_CLSVAL + tid] = lds<int>(v.base + L.clsval)[tid];
                 }
-                int cv[CLS];
-#pragma unroll
-                for (int r = 0; r < CLS; ++r) cv[r] = (r < ncls_old) ? lds<int>(v.base + L.clsval)[r] : 0;
                 PM2_BARRIER();
 #pragma unroll
                 for (int uu = 0; uu < PPL; ++uu) {
                     const int p = tid * PPL + uu;
                     const int r = rk[uu];
-                    int ns_ = 0, cvr = 0;
-#pragma unroll
-                    for (int r2 = 0; r2 < CLS; ++r2) if (r2 == r) { ns_ = newslot[r2]; cvr = cv[r2]; }
+                    const int ns_ = redi[RI_NEWSLOT + r];
                     rk[uu] = ns_;
-                    if (redi[36 + r] == p) {
-                        lds<int>(v.base + L.clsval)[ns_] = cvr; lds<int>(v.base + L.clslead)[ns_] = p; lds<int>(v.base + L.leadcol)[ns_] = ck[uu];
+                    if (redi[RI_CLSMIN + r] == p) {
+                        lds<int>(v.base + L.clsval)[ns_] = redi[RI_CLSVAL + r]; lds<int>(v.base + L.clslead)[ns_] = p; lds<int>(v.base + L.leadcol)[ns_] = ck[uu];
                     }
                 }
                 col_put(k, ck);
@@ -1467,6 +1543,7 @@ struct Sweep2 {
             }
             PM2_BARRIER();
         }
+        PHR(15);
     }
 
     // ---- the whole sweep -----------------------------------------------------------------------------------------------------------
@@ -1478,6 +1555,7 @@ struct Sweep2 {
         N = a.N; P = a.P; n = a.n; n1 = a.n1; iter = a.iter;
         seed = a.seed + (unsigned long long)chain;
         const long long t_start = PM2_CLOCK();
+        const long long t_wall = a.phase ? PM2_WALLCLOCK() : 0ll;
         const bool owner = wave < K;
         auto order = PM2_G(const int, a.order) + (size_t)chain * n;
         auto logphi = PM2_G(const double, a.logphi) + (size_t)chain * a.npairs;
@@ -1498,22 +1576,6 @@ struct Sweep2 {
 #endif
         if (a.phase && tid == 0) ph_last = PM2_CLOCK();
         PM2_BARRIER();
-        if (tid == 0) {
-            // leaf decomposition of Julia's accumulate_pairwise! over [1, P) and its recursion as a post-order program
-            int nl = 0, np = 0, sp = 0;
-            int *st_i1 = lds<int>(L.tr), *st_n = st_i1 + 24, *st_stage = st_i1 + 48;      // (the recursion's stack: LDS, not scratch)
-            int *li1 = lds<int>(L.leaf_i1), *ln = lds<int>(L.leaf_n);
-            u8 *prog = lds<u8>(L.leaf_prog);
-            st_i1[0] = 1; st_n[0] = P - 1; st_stage[0] = 0;
-            while (sp >= 0) {
-                const int i1 = st_i1[sp], nn = st_n[sp];
-                if (nn < 128) { li1[nl] = i1; ln[nl] = nn; ++nl; prog[np++] = 0; --sp; }
-                else if (st_stage[sp] == 0) { st_stage[sp] = 1; prog[np++] = 3; ++sp; st_i1[sp] = i1; st_n[sp] = nn >> 1; st_stage[sp] = 0; }
-                else if (st_stage[sp] == 1) { st_stage[sp] = 2; prog[np++] = 1; const int n2 = nn >> 1; ++sp; st_i1[sp] = i1 + n2; st_n[sp] = nn - n2; st_stage[sp] = 0; }
-                else { prog[np++] = 2; --sp; }
-            }
-            sc()[SC_NLEAF] = nl; sc()[SC_NPROG] = np;
-        }
 #pragma unroll
         for (int u = 0; u < PPL; ++u) lw.set(u, a.lw_init);
 #pragma unroll
@@ -1680,8 +1742,10 @@ struct Sweep2 {
                 if (lane == 0) { red[8 + wave] = sa; red[12 + wave] = sq; }
             }
             if (owner) phase_c(wave, x, pos);
+            PHC(9);
             PH2(6);
             PM2_BARRIER();
+            PHC(15);
             PH2(7);
             if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
             // ---- every particle follows its group: new column, new class slot
@@ -1749,7 +1813,10 @@ struct Sweep2 {
                 else if (a.requeue) {
                     PM2_G(int, a.requeue)[chain] = 1;                                      // sweep again with the general kernel
                     if (a.handed) PM2_G(int, a.handed)[chain] = a.sweep_no;
-                    if (a.requeue_total) { pm2_atomic_add((u64 *)a.requeue_total + 3, (u64)1); pm2_atomic_add((u64 *)a.requeue_total + (failed - 2), (u64)1); }
+                    if (a.requeue_total) {
+                        pm2_atomic_add((u64 *)a.requeue_total + 3, (u64)1); pm2_atomic_add((u64 *)a.requeue_total + (failed - 2), (u64)1);
+                        if (failed == 4 && sc()[SC_TMP1] > 2 * CLS) pm2_atomic_add((u64 *)a.requeue_total + 1, (u64)1);      // (how many of them would not fit twice the classes either)
+                    }
                 }
                 else PM2_G(int, a.err)[chain] = PMDI_S2_REQUEUE;                           // (no requeue list: report it)
                 // (the general kernel may sweep the chain with K cooperating workgroups that ADD their counters)
@@ -1769,6 +1836,7 @@ struct Sweep2 {
         PH2(10);
         if (a.phase && tid == 0) {
             lds<long long>(L.ph)[14] = PM2_CLOCK() - t_start;
+            lds<long long>(L.ph)[12] = t_wall; lds<long long>(L.ph)[13] = PM2_WALLCLOCK();      // when the chain ran (launch timeline)
             for (int e = 0; e < 16; ++e) PM2_G(long long, a.phase)[(size_t)chain * 16 + e] = lds<long long>(L.ph)[e];
         }
 #undef PH2

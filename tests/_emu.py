@@ -13,24 +13,26 @@ _LIB = os.path.join(_EMU, "libpmdi_emu.so")
 _CSRC = os.path.join(os.path.dirname(_HERE), "particlemdi.jl_amd", "csrc")
 
 
-def build(force=False):
+VARIANTS = {"": [], "xcap2": ["-DPM2_XCAP=2"]}      # (xcap2: two LDS entries for uncached clusters, so that the arena list is exercised)
+
+
+def build(force=False, variant=""):
+    _LIB = os.path.join(_EMU, f"libpmdi_emu{'_' + variant if variant else ''}.so")
     deps = [os.path.join(_EMU, "emu_sweep2.cpp"), os.path.join(_EMU, "wavesim.h")] + \
            [os.path.join(_CSRC, f) for f in ("pmdi_sweep2_body.h", "pmdi_arith.h", "pmdi_internal.h")]
     if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(d) for d in deps):
         return _LIB
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unknown-pragmas",
-                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(_EMU, "emu_sweep2.cpp"), "-o", _LIB])
+                           "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + VARIANTS[variant] + [os.path.join(_EMU, "emu_sweep2.cpp"), "-o", _LIB])
     return _LIB
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_LIB)
+def lib(variant=""):
+    if variant not in _libs:
+        L = C.CDLL(build(variant=variant))
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.emu_create.restype = vp
         L.emu_create.argtypes = [i32, i64, i32, i32, vp, vp, C.c_uint64, i32, i32, i32]
@@ -39,8 +41,8 @@ def lib():
         L.emu_lds_bytes.argtypes = [vp]
         L.emu_sweep.restype = C.c_int
         L.emu_sweep.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, dbl] + [vp] * 10
-        _lib = L
-    return _lib
+        _libs[variant] = L
+    return _libs[variant]
 
 
 def _ptr(a):
@@ -50,20 +52,21 @@ def _ptr(a):
 class EmuSweeper:
     """One chain of the settled-chain kernel on the emulator; same call shape as the oracle's Oracle.sweep."""
 
-    def __init__(self, data, N, P, seed=0, q1_mode=0, cols_l=64, idcap=128):
+    def __init__(self, data, N, P, seed=0, q1_mode=0, cols_l=64, idcap=128, variant=""):
+        self._L = lib(variant)
         self.K, self.n, self.N, self.P = len(data), int(data[0].shape[0]), int(N), int(P)
         self.D = np.array([x.shape[1] for x in data], dtype=np.int32)
         self._x = [np.ascontiguousarray(x, dtype=np.float64) for x in data]
         ptrs = (C.c_void_p * self.K)(*[x.ctypes.data for x in self._x])
-        self.h = lib().emu_create(self.K, self.n, self.N, self.P, _ptr(self.D), C.cast(ptrs, C.c_void_p), int(seed), int(q1_mode),
+        self.h = self._L.emu_create(self.K, self.n, self.N, self.P, _ptr(self.D), C.cast(ptrs, C.c_void_p), int(seed), int(q1_mode),
                                   int(cols_l), int(idcap))
         if not self.h:
             raise ValueError("emu_create rejected the configuration")
-        self.lds_bytes = lib().emu_lds_bytes(self.h)
+        self.lds_bytes = self._L.emu_lds_bytes(self.h)
 
     def close(self):
         if self.h:
-            lib().emu_destroy(self.h)
+            self._L.emu_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -87,7 +90,7 @@ class EmuSweeper:
         tr = np.zeros((n - n1 + 1, 2 + 2 * K)) if trace else None
         particle = np.zeros((K, P, N), dtype=np.int32); counts = np.zeros((K, cap), dtype=np.int32); cn = np.zeros((K, cap), dtype=np.int32)
         mx = np.zeros(K, dtype=np.int32)
-        err = lib().emu_sweep(self.h, int(it), _ptr(s_in), _ptr(order), int(n1), _ptr(Pi_in), _ptr(lphi), _ptr(fl), float(lw_init),
+        err = self._L.emu_sweep(self.h, int(it), _ptr(s_in), _ptr(order), int(n1), _ptr(Pi_in), _ptr(lphi), _ptr(fl), float(lw_init),
                               _ptr(s_out), _ptr(lw), _ptr(pstar), _ptr(stats), _ptr(work), _ptr(tr), _ptr(particle), _ptr(counts), _ptr(cn), _ptr(mx))
         out = {"err": err, "why": int(stats[7]), "s": s_out.T.astype(np.int64) + 1, "logweight": lw, "p_star": int(pstar[0]) + 1,
                "stats": dict(zip(("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"), stats[:5].tolist())),

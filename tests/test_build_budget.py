@@ -46,3 +46,30 @@ def test_spill_budget_of_the_sweep_kernel_builds():
     for variant, limit in BUDGET.items():
         assert variant in spills, (variant, sorted(spills))
         assert spills[variant] <= limit, f"pmdi_sweep_kernel<{variant}> spills {spills[variant]} VGPRs (budget {limit})"
+
+
+SRC2 = os.path.join(ROOT, "particlemdi.jl_amd", "csrc", "pmdi_sweep2.hip")
+BUDGET2 = 32          # VGPR spill slots of any <K, PPL> build of the settled-chain kernel (256 registers, two workgroups per CU);
+#                       round 3 measures 0..25.  Before the per-lane state moved from member arrays to scalar fields (RegArr) the
+#                       whole object sat in scratch (138 slots) and a step cost three times as much.
+
+
+def test_spill_budget_of_the_settled_chain_kernel_builds():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    with tempfile.TemporaryDirectory() as tmp:
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                            "--cuda-device-only", "-c", SRC2, "-o", os.path.join(tmp, "x.o"),
+                            "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cur, seen = None, {}
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: \S*pmdi_sweep2_kernelILi(\d)ELi(\d)E", line)
+        if m:
+            cur = (int(m.group(1)), int(m.group(2)))
+        m = re.search(r"VGPRs Spill: (\d+)", line)
+        if m and cur:
+            seen[cur] = int(m.group(1))
+            cur = None
+    assert len(seen) == 12, sorted(seen)
+    for variant, n in seen.items():
+        assert n <= BUDGET2, f"pmdi_sweep2_kernel<{variant[0]}, {variant[1]}> spills {n} VGPRs (budget {BUDGET2})"

@@ -15,12 +15,12 @@ def _gauss(rng, n, K, D=12, sep=3.0):
     return [rng.normal(size=(n, D + k)) + sep * (z[:, None] - 1) for k in range(K)], z
 
 
-def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0):
+def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0, variant=""):
     from _emu import EmuSweeper
     rng = np.random.default_rng(seed)
     n, K = data[0].shape[0], len(data)
     kinds = ["gaussian"] * K
-    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap)
+    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant)
     o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1)
     rec = o.debug_steps(n - n1 + 1)
     requeued = []
@@ -64,7 +64,7 @@ def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=
     return rec
 
 
-def _chain(O, data, N, P, seed, burn, iters, q1=0, cols_l=64, idcap=128, allow_requeue=0, flags=None):
+def _chain(O, data, N, P, seed, burn, iters, q1=0, cols_l=64, idcap=128, allow_requeue=0, flags=None, variant=""):
     """A real Gibbs chain (the oracle's hyper-parameter updates): `burn` iterations on the oracle alone from the random start of
     src/pmdi.jl:63-66, then `iters` iterations swept by both."""
     from _emu import EmuSweeper
@@ -72,7 +72,7 @@ def _chain(O, data, N, P, seed, burn, iters, q1=0, cols_l=64, idcap=128, allow_r
     n1 = max(1, n // 4)
     hy = O.Hypers(n, N, K, seed=seed)
     o = O.Oracle(data, ["gaussian"] * K, N, P, seed=seed, q1_mode=q1)
-    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap)
+    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant)
     rec = o.debug_steps(n - n1 + 1)
     requeued, compared = [], 0
     for it in range(1, burn + iters + 1):
@@ -127,6 +127,15 @@ def test_arena_fallback_of_the_lds_tables(O):
     rng = np.random.default_rng(6)
     data, z = _gauss(rng, 160, 2, sep=3.0)
     _compare(O, data, 6, 256, 2, 31, 40, settle=True, truth=z, cols_l=2, idcap=8, allow_requeue=0)
+
+
+def test_uncached_clusters_beyond_the_lds_list(O):
+    """A build with two LDS entries for uncached reachable clusters (PM2_XCAP=2) and eight cacheable ids: the clusters a class leader
+    reaches beyond that are listed and evaluated through the arena (four per round), same results, nothing is handed back for it."""
+    rng = np.random.default_rng(12)
+    data, z = _gauss(rng, 200, 2, sep=2.0)
+    _compare(O, data, 10, 256, 2, 61, 50, settle=True, truth=z, cols_l=64, idcap=8, allow_requeue=0, variant="xcap2", scramble=0.3)
+    assert _chain(O, data, 10, 256, 13, 3, 2, idcap=8, allow_requeue=0, variant="xcap2") >= 2
 
 
 def test_feature_flags(O):
