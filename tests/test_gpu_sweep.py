@@ -361,11 +361,12 @@ def test_settled_chain_kernel_equals_oracle(pkg, O, monkeypatch, K, P, n, N):
 
 
 def test_settled_chain_kernel_hands_back_what_does_not_fit(pkg, O, monkeypatch):
-    """From the random start of src/pmdi.jl:63-66 a chain has dozens of particle classes: forced onto the settled-chain kernel it is
-    handed back at once and the general kernel sweeps it: results equal the oracle's, and the counter of handed-back chains moves."""
+    """From the random start of src/pmdi.jl:63-66 a chain has dozens of particle classes (more than the sixteen the settled-chain
+    kernel holds per dataset): forced onto that kernel it is handed back at once and the general kernel sweeps it: results equal the
+    oracle's, and the counter of handed-back chains moves."""
     monkeypatch.setenv("PMDI_SETTLED", "2")
     monkeypatch.setenv("PMDI_KSPLIT", "0")
     rng = np.random.default_rng(77)
-    data, _ = _gauss_planted(rng, 200, 2, sep=1.0)
-    g = _compare_run(pkg, O, data, ["gaussian"] * 2, 8, 256, 2, 78, 50)
+    data, _ = _gauss_planted(rng, 200, 2, sep=0.5)
+    g = _compare_run(pkg, O, data, ["gaussian"] * 2, 20, 1024, 2, 78, 50)
     assert g.sw.settled and g.sw.given_back()[3] >= 1
