@@ -285,6 +285,9 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
     hipError_t e;
     a.err_keep = h->err_keep;
     a.sweep_no = ++h->sweep_no;        // (counts the sweeps of this handle: how long ago was a chain given back?)
+    // nobody is on the list of given-back chains when a sweep starts (a chain whose re-run failed must not be swept by two launches
+    // of the next sweep at once)
+    if (h->s2_ok) HIP_TRY(hipMemsetAsync(h->d_requeue.p, 0, (size_t)C * 4, st));
     if (h->ksplit) {       // arrival counters of the hand-offs; the K workgroups of a chain ADD their counters into stats
         HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, st));
         HIP_TRY(hipMemsetAsync(a.stats, 0, (size_t)C * 64, st));
@@ -337,6 +340,12 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (settled chains): %s", hipGetErrorString(e));
             SweepArgs ar = al;
             ar.group_flag = nullptr; ar.requeue_only = 1;
+            // ... with one workgroup per dataset when the model has several (the latency form: a chain that is swept twice should at
+            // least be swept fast the second time -- it is the tail of the whole sweep)
+            if (h->cfg.K > 1 && h->d_xcnt.p && !(getenv("PMDI_REQUEUE_KSPLIT") && atoi(getenv("PMDI_REQUEUE_KSPLIT")) == 0)) {
+                ar.ksplit = 1;
+                HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, h->stream2));
+            }
             e = launch_one(h, ar, (SweepArgs *)h->d_args5.p, C, 256, h->stream2);
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (chains given back by the settled-chain kernel): %s", hipGetErrorString(e));
         } else {
@@ -617,7 +626,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         // automatic width: split the chains of a sweep into a heavy and a light launch
         h->split = cfg->block_threads == 0 && (h->T > 256 || h->s2_ok) && env_int("PMDI_SPLIT", 1) != 0;
         if (!h->split) h->s2_ok = false;
-        h->light_ids = env_int("PMDI_LIGHT_IDS", 40);
+        // with the settled-chain kernel every chain is "light" until that kernel gives it back (it evaluates any number of live
+        // clusters in place, slower per step but still ahead of the general kernel); without it: few live clusters per step
+        h->light_ids = env_int("PMDI_LIGHT_IDS", h->s2_ok ? 1000000 : 40);
         if (h->split) {
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
         }
@@ -676,7 +687,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 }
         }
     }
-    if (h->ksplit && ((rc = h->d_xcnt.ensure((size_t)C * 32 * 4)) || (rc = h->d_xinc.ensure((size_t)C * 2 * K * P * 8)) ||
+    if ((h->ksplit || (h->s2_ok && K > 1 && (long long)K * n < (1LL << 27))) && ((rc = h->d_xcnt.ensure((size_t)C * 32 * 4)) || (rc = h->d_xinc.ensure((size_t)C * 2 * K * P * 8)) ||
                       (rc = h->d_xlab.ensure((size_t)C * 2 * K * P * 4)) || (rc = h->d_xhdr.ensure((size_t)C * 2 * K * 16))))
         return bail(rc);
     if (cfg->q2_mode == 1 &&       // ancestor log of the resampling events: up to one per swept observation

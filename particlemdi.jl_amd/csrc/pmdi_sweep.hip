@@ -1339,7 +1339,7 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
                 if (a.requeue) a.requeue[chain] = 0;
             } else {
                 // the K workgroups of the chain add their datasets' counters (the host zeroed stats and err before the launch)
-                if (kd0 == 0) { a.pstar[chain] = pstar; st[ST_NRESAMPLE] = sh.stat[1]; }
+                if (kd0 == 0) { a.pstar[chain] = pstar; st[ST_NRESAMPLE] = sh.stat[1]; if (a.requeue_only && a.requeue) a.requeue[chain] = 0; }
                 atomicAdd((unsigned long long *)&st[ST_NOPS], (unsigned long long)sh.stat[0]);
                 atomicAdd((unsigned long long *)&st[ST_NCLONES], (unsigned long long)sh.stat[2]);
                 atomicMax((unsigned long long *)&st[ST_MAXID], (unsigned long long)sh.stat[3]);

@@ -377,6 +377,7 @@ PM2_DEV double wave_min_d(double v)
 }
 #endif
 // exclusive prefix sum of an int over the wave, and the total
+#ifdef PM2_EMU
 PM2_DEV int wave_excl_scan_i(int v, int &total)
 {
     const int lane = PM2_TID() & 63;
@@ -385,6 +386,21 @@ PM2_DEV int wave_excl_scan_i(int v, int &total)
     total = shfl_i(inc, 63);
     return inc - v;
 }
+#else
+// (the DPP network: shifts inside the rows of sixteen lanes, then the row totals broadcast into the rows above; all lanes active)
+PM2_DEV int wave_excl_scan_i(int v, int &total)
+{
+    int inc = v;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);      // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);      // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);      // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);      // row_shr:8
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    total = __builtin_amdgcn_readlane(inc, 63);
+    return inc - v;
+}
+#endif
 // set bits strictly below bit p of a bitmap of 64-bit words
 PM2_DEV int popc_below64(const u64 *bm, int p)
 {
@@ -486,7 +502,7 @@ struct Sweep2 {
 
     // ---- cluster cache (owner wave) -------------------------------------------------------------------------------------------
     // load the statistics of cluster `id` into slot s0 (uniform) of the owner wave: lane = feature
-    PM2_DEV void cache_fill(const DV &v, int k, int s0, double sg, double bt, int cnv, bool defer = false)
+    PM2_DEV void cache_fill(const DV &v, int k, int s0, double sg, double bt, int cnv, bool defer = false, bool have_g = false, double g_in = 0.0)
     {
         double mu, lam;
         pmdi_arith::gauss_ml(cnv, sg, bt, mu, lam);
@@ -496,7 +512,7 @@ struct Sweep2 {
         if (lane < v.D) v.ta_row(s0)[lane] = 0.5 * log(lam / ((double)cnv + 1.0));            // gaussian_cluster.jl:45
         if (lane == 0) {
             lds<int>(v.base + L.slot_cn)[s0] = cnv;
-            const double g = PM2_G(const double, ap->ds[k].gtab)[cnv];            // gaussian_cluster.jl:38-40
+            const double g = have_g ? g_in : PM2_G(const double, ap->ds[k].gtab)[cnv];            // gaussian_cluster.jl:38-40
             // (deferred: the load stays in flight; the next cluster phase of this wave writes the value where the ordered sums read it)
             if (defer) { pend_g = g; pend_slot = s0; }
             else lds<double>(v.base + L.slot_g)[s0] = (double)v.dsc()[DS_NFLAG] * g;
@@ -992,6 +1008,20 @@ struct Sweep2 {
         // classes of the next step: one per distinct value, leader = lowest first particle, slots in leader order
         PHC(4);
         int nrep = 0;
+        int kv_r = 0;                    // nk <= 64: lane j keeps its key's class value, first particle | column, and representative flag
+        unsigned mp_r = INFU;
+        bool rep_r = false;
+        if (nk <= 64) {
+            if (lane < nk) { kv_r = kval[lane]; mp_r = minp[klist[lane]]; }
+            rep_r = lane < nk;
+            for (int j2 = 0; j2 < nk; ++j2) {
+                const int v2 = readlane_i(kv_r, j2);
+                const unsigned m2 = (unsigned)readlane_i((int)mp_r, j2);
+                if (v2 == kv_r && m2 < mp_r) rep_r = false;
+            }
+            if (lane < nk) krep[lane] = rep_r ? (u8)1 : (u8)0;
+            nrep = pm2_popc64(PM2_BALLOT(rep_r));
+        } else
         for (int j0 = 0; j0 < nk; j0 += 64) {
             const int j = j0 + lane;
             bool rep = false;
@@ -1033,7 +1063,36 @@ struct Sweep2 {
             int tot;
             const int base = ncol_new + wave_excl_scan_i(nnew, tot);
             if (cc < ncol) { v.wmask_set(cc, wm); v.cbi_set(cc, (base << 8) | (inpl + 1)); }
-            // the copies, then the in-place entry (the copies read the column as it was)
+            // the copies, then the in-place entries (the copies read the columns as they were).  The copies of the chunk are independent
+            // of each other: they are listed (source column, label) in the dataset's transient rows -- dead in this phase -- and made
+            // 64 / N at a time, lanes = (copy, label); only a chunk with more copies than the list holds takes the column-by-column loop
+            unsigned *jobs = lds<unsigned>(v.trb + L.tr_tb);
+            const int jobcap = L.tr_stride / 4;
+            if (tot <= jobcap) {
+                if (cc < ncol && nnew > 0) {
+                    int idx = base - ncol_new;
+                    u64 wm0 = wm;
+                    while (wm0) {
+                        const int ns = pm2_ffs64(wm0) - 1;
+                        wm0 &= wm0 - 1;
+                        if (ns != inpl) jobs[idx++] = ((unsigned)cc << 8) | (unsigned)ns;
+                    }
+                }
+                PM2_WAVE_BARRIER();
+                const int G = 64 / N;
+                const int g = lane / N, nn = lane - g * N;
+                for (int j0 = 0; j0 < tot; j0 += G) {
+                    if (g < G && j0 + g < tot) {
+                        const unsigned job = jobs[j0 + g];
+                        const int cs = (int)(job >> 8), ns = (int)(job & 0xffu);
+                        int val = v.tab_get(cs, nn);
+                        if (nn == ns) val = v.tgt_get(val);
+                        v.tab_set(ncol_new + j0 + g, nn, val);
+                    }
+                }
+                PM2_WAVE_BARRIER();                            // (the copies have read the columns as they were)
+                if (cc < ncol && inpl >= 0) v.tab_set(cc, inpl, v.tgt_get(v.tab_get(cc, inpl)));
+            } else {
             u64 m;
             bool todo = wm != 0;
             while ((m = PM2_BALLOT(todo)) != 0) {
@@ -1056,21 +1115,42 @@ struct Sweep2 {
                 if (inpl0 >= 0 && lane == 0) v.tab_set(cs, inpl0, v.tgt_get(v.tab_get(cs, inpl0)));
                 if (lane == l0) todo = false;
             }
+            }
             ncol_new += tot;
         }
         PM2_WAVE_BARRIER();
         // the class list of the next step and every key's class slot; the leader's column after the split
         PHC(6);
+        unsigned mpr_r = INFU;            // nk <= 64: the first particle | column of the lane's class representative, and the class slot
+        int slot_r = 0;
+        if (nk <= 64) {
+            const u64 repb = PM2_BALLOT(rep_r);
+            for (u64 rb = repb; rb; rb &= rb - 1) {
+                const int j2 = pm2_ffs64(rb) - 1;
+                const int v2 = readlane_i(kv_r, j2);
+                const unsigned m2 = (unsigned)readlane_i((int)mp_r, j2);
+                if (v2 == kv_r) mpr_r = m2;
+            }
+            for (u64 rb = repb; rb; rb &= rb - 1) {
+                const int j2 = pm2_ffs64(rb) - 1;
+                const unsigned m2 = (unsigned)readlane_i((int)mp_r, j2);
+                if (m2 < mpr_r) ++slot_r;
+            }
+        }
         for (int j0 = 0; j0 < nk; j0 += 64) {
             const int j = j0 + lane;
             if (j < nk) {
                 const int key = klist[j];
                 const int v0 = kval[j];
-                int jr = j;
-                for (int j2 = 0; j2 < nk; ++j2) if (krep[j2] && kval[j2] == v0) jr = j2;
-                const unsigned mpr = minp[klist[jr]];
-                int slot = 0;
-                for (int j2 = 0; j2 < nk; ++j2) if (krep[j2] && minp[klist[j2]] < mpr) ++slot;
+                unsigned mpr = mpr_r;
+                int slot = slot_r;
+                if (nk > 64) {
+                    int jr = j;
+                    for (int j2 = 0; j2 < nk; ++j2) if (krep[j2] && kval[j2] == v0) jr = j2;
+                    mpr = minp[klist[jr]];
+                    slot = 0;
+                    for (int j2 = 0; j2 < nk; ++j2) if (krep[j2] && minp[klist[j2]] < mpr) ++slot;
+                }
                 lds<u8>(v.base + L.knew)[key] = (u8)slot;
                 if (krep[j]) {
                     const int pl = (int)(mpr >> 16), cl = (int)(mpr & 0xffffu);
@@ -1102,18 +1182,35 @@ struct Sweep2 {
         // first cluster's were fetched at the top of the phase), written to the pool; a cached cluster gets its mu, lambda and first
         // term refreshed in the owner wave's registers
         {
+            // Four clusters at a time: their table entries, then their statistics and prefix constants (all loads in flight together),
+            // then the arithmetic.  A chain whose particles sit on dozens of private columns updates dozens of clusters per step.
             auto sb = PM2_G(double, v.ar.sb());
-            for (int e = 0; e < nd; ++e) {
-                const int c = chosen(e);
-                const int t = v.tgt_get(c);
-                const int nnew = v.cn_get(t);
-                const int s0 = v.slot_of(c);
-                double sg = pf_sg, bt = pf_bt;
-                if (e > 0 && lane < D) { sg = sb[((size_t)c * D + lane) * 2]; bt = sb[((size_t)c * D + lane) * 2 + 1]; }
-                const bool on = lane < D && fl[lane];
-                if (on) pmdi_arith::gauss_add_sb(x, nnew, sg, bt);
-                if (lane < D && (on || t != c)) { sb[((size_t)t * D + lane) * 2] = sg; sb[((size_t)t * D + lane) * 2 + 1] = bt; }
-                if (s0 != NONE8 && t == c) cache_fill(v, k, s0, sg, bt, nnew);
+            const bool on = lane < D && fl[lane];
+            for (int e0 = 0; e0 < nd; e0 += 4) {
+                int cj[4], tj[4], nj[4], sj[4];
+                double sgj[4], btj[4], gj[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cj[j] = 0; tj[j] = 0; nj[j] = 0; sj[j] = NONE8;
+                    if (e0 + j < nd) { cj[j] = chosen(e0 + j); tj[j] = v.tgt_get(cj[j]); nj[j] = v.cn_get(tj[j]); sj[j] = v.slot_of(cj[j]); }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sgj[j] = pf_sg; btj[j] = pf_bt; gj[j] = 0.0;
+                    if (e0 + j < nd) {
+                        if (e0 + j > 0 && lane < D) { sgj[j] = sb[((size_t)cj[j] * D + lane) * 2]; btj[j] = sb[((size_t)cj[j] * D + lane) * 2 + 1]; }
+                        if (sj[j] != NONE8 && tj[j] == cj[j] && lane == 0) gj[j] = PM2_G(const double, d.gtab)[nj[j]];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (e0 + j < nd) {
+                        double sg = sgj[j], bt = btj[j];
+                        if (on) pmdi_arith::gauss_add_sb(x, nj[j], sg, bt);
+                        if (lane < D && (on || tj[j] != cj[j])) { sb[((size_t)tj[j] * D + lane) * 2] = sg; sb[((size_t)tj[j] * D + lane) * 2 + 1] = bt; }
+                        if (sj[j] != NONE8 && tj[j] == cj[j]) cache_fill(v, k, sj[j], sg, bt, nj[j], false, true, gj[j]);
+                    }
+                }
             }
         }
         PHD(15);
@@ -1315,12 +1412,18 @@ struct Sweep2 {
         PM2_BARRIER();
         PHR(4);
         // slot j belongs to the first particle with J_p > j
+        {
+            // (the lane's slots are consecutive: the answer never moves down, and the same heavy particle usually owns the next slot too)
+            int lo = 0;
 #pragma unroll
-        for (int uu = 0; uu < PPL; ++uu) {
-            const int j = tid * PPL + uu;
-            int lo = 0, hi = P - 1;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)jtab[mid] > j) hi = mid; else lo = mid + 1; }
-            raw[j] = (u16)lo;
+            for (int uu = 0; uu < PPL; ++uu) {
+                const int j = tid * PPL + uu;
+                if (uu == 0 || !((int)jtab[lo] > j)) {
+                    int hi = P - 1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)jtab[mid] > j) hi = mid; else lo = mid + 1; }
+                }
+                raw[j] = (u16)lo;
+            }
         }
         int js = (int)(usl * (double)P);                      // shuffle!, partstar[1] = 1, sort! (:43-45)
         if (js >= P) js = P - 1;
@@ -1370,25 +1473,34 @@ struct Sweep2 {
             PHR(7);
 #pragma unroll
             for (int uu = 0; uu < PPL; ++uu) {
-                // particles per old column, aggregated over the lanes that took the same one
-                const int cl = ck[uu];
-                u64 rem = ~0ull;
-                while (rem) {
-                    const int l0 = pm2_ffs64(rem) - 1;
-                    const int c0 = readlane_i(cl, l0);
-                    const u64 m = PM2_BALLOT(cl == c0);
-                    if (lane == l0) {
-                        // (u16 table, 32-bit LDS atomics: two columns share a word)
-                        unsigned *wd = (unsigned *)mult + (c0 >> 1);
-                        pm2_atomic_add(wd, (unsigned)pm2_popc64(m) << ((c0 & 1) * 16));
-                    }
-                    rem &= ~m;
+                // particles per old column and the lowest particle of every class.  The ancestors are sorted, so the particles of a lane --
+                // and mostly of a whole wave -- sit on the same column and class: runs inside the lane are counted once, and a wave whose
+                // runs all agree speaks through one lane
+                const int cl = ck[uu], r = rk[uu];
+                bool start = true;
+                if (uu > 0) start = cl != ck[uu - 1] || r != rk[uu - 1];
+                int cnt = 1;
+                {
+                    bool go = true;
+#pragma unroll
+                    for (int u2 = uu + 1; u2 < PPL; ++u2) { go = go && ck[u2] == cl && rk[u2] == r; cnt += go ? 1 : 0; }
                 }
-                // lowest particle of every class
-                const int r = rk[uu];
-                for (int rr = 0; rr < ncls_old; ++rr) {
-                    const u64 m = PM2_BALLOT(r == rr);
-                    if (m && lane == pm2_ffs64(m) - 1) pm2_atomic_min(&lds<int>(L.red)[RI_CLSMIN + rr], tid * PPL + uu);
+                const u64 act = PM2_BALLOT(start);
+                if (act) {
+                    const int l0 = pm2_ffs64(act) - 1;
+                    const int key = cl * CLS + r;
+                    const bool uni = PM2_BALLOT(start && key == readlane_i(key, l0)) == act;
+                    int tot = cnt;
+                    if (uni) {
+                        tot = 0;
+#pragma unroll
+                        for (int c_ = 1; c_ <= PPL; ++c_) tot += c_ * pm2_popc64(PM2_BALLOT(start && cnt == c_));
+                    }
+                    if (uni ? (lane == l0) : start) {
+                        // (u16 table, 32-bit LDS atomics: two columns share a word)
+                        pm2_atomic_add((unsigned *)mult + (cl >> 1), (unsigned)tot << ((cl & 1) * 16));
+                        pm2_atomic_min(&lds<int>(L.red)[RI_CLSMIN + r], tid * PPL + uu);
+                    }
                 }
             }
             PM2_BARRIER();
@@ -1812,6 +1924,7 @@ struct Sweep2 {
                 if (failed == 1) PM2_G(int, a.err)[chain] = -4;                            // PMDI_E_POOL
                 else if (a.requeue) {
                     PM2_G(int, a.requeue)[chain] = 1;                                      // sweep again with the general kernel
+                    if (!a.err_keep) PM2_G(int, a.err)[chain] = 0;                         // (its K cooperating workgroups only ever write an error)
                     if (a.handed) PM2_G(int, a.handed)[chain] = a.sweep_no;
                     if (a.requeue_total) {
                         pm2_atomic_add((u64 *)a.requeue_total + 3, (u64)1); pm2_atomic_add((u64 *)a.requeue_total + (failed - 2), (u64)1);

@@ -83,7 +83,7 @@ if os.environ.get("PMDI_PHASE_TIMERS"):
         print("   last to end: " + ", ".join(f"[start {st_[i]:.0f} dur {en_[i] - st_[i]:.0f}]" for i in late))
     print("mean over chains, per observation: " + " ".join(f"{nm} {allph[:, i].mean() / n_s / 1e3:.2f}k" for i, nm in enumerate(names) if nm)
           + f" | whole sweep {allph[:, 14].mean() / n_s / 1e3:.2f}k")
-    for c in np.argsort(cs)[[0, C // 4, C // 2, 3 * C // 4, C - 1]]:
+    for c in np.argsort(cs)[[0, C // 4, C // 2, 3 * C // 4, C - 6, C - 5, C - 4, C - 3, C - 2, C - 1]]:
         ph = sw.phase_timers(int(c)).astype(np.float64)
         tot = ph[14] if ph[14] > 0 else ph[:10].sum()
         nres = g.results()["stats"][c, 1]
