@@ -158,7 +158,7 @@ constexpr unsigned INFU = 0xFFFFFFFFu;
 constexpr int PMDI_S2_REQUEUE = 1;   // err code: sweep this chain again with the general kernel
 
 // per-dataset scalars (ints in LDS)
-enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_NDX, DS_UNUSED, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_FOLLOW, DS_DIRTY, DS_NEEDMASK, DS_CHANGED, DS_COUNT = 16 };
+enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_NDX, DS_ND, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_FOLLOW, DS_DIRTY, DS_NEEDMASK, DS_CHANGED, DS_NDLOW, DS_COUNT = 16 };
 // shared scalars
 enum { SC_FAIL = 0, SC_RES, SC_PSTAR, SC_NLEAF, SC_NPROG, SC_JS, SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3, SC_COUNT = 16 };
 
@@ -604,7 +604,7 @@ struct Sweep2 {
             int nf = 0;
             for (int q = 0; q < D; ++q) nf += fl[q];
             dsc[DS_NFLAG] = nf; dsc[DS_MAXID] = nu + 1; dsc[DS_NCLS] = 1; dsc[DS_NCOL] = 1; dsc[DS_NDX] = 0; dsc[DS_NX] = 0;
-            dsc[DS_DIRTY] = 1; dsc[DS_CHANGED] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_NEEDMASK] = 0; dsc[DS_NCLONE] = 0;
+            dsc[DS_DIRTY] = 1; dsc[DS_CHANGED] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_NEEDMASK] = 0; dsc[DS_NCLONE] = 0; dsc[DS_ND] = 0; dsc[DS_NDLOW] = 0;
             lds<int>(v.base + L.clsval)[0] = 1; lds<int>(v.base + L.clslead)[0] = 0; lds<int>(v.base + L.leadcol)[0] = 0;
         }
         PM2_WAVE_BARRIER();
@@ -945,7 +945,7 @@ struct Sweep2 {
                     pm2_atomic_max((u64 *)&st[3], (u64)maxid);
                     long long *w_ = wk(k);
                     w_[WK_EVAL] += dsc[DS_NNEED]; w_[WK_UPD] += 1;
-                    dsc[DS_NDX] = 0; dsc[DS_NCLONE] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_DIRTY] = 0; dsc[DS_CHANGED] = 0;
+                    dsc[DS_NDX] = 0; dsc[DS_NCLONE] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_DIRTY] = 0; dsc[DS_CHANGED] = 0; dsc[DS_ND] = 0;
                 }
                 return true;
             }
@@ -1178,37 +1178,48 @@ struct Sweep2 {
 #endif
         PHD(13);
         PHC(7);
+        int ndefer = 0;
         // -- C4: deepcopy + cluster_add! of every distinct chosen cluster (:297,:300), lane = feature: (Sigma, beta) from the pool (the
         // first cluster's were fetched at the top of the phase), written to the pool; a cached cluster gets its mu, lambda and first
         // term refreshed in the owner wave's registers
         {
-            // Four clusters at a time: their table entries, then their statistics and prefix constants (all loads in flight together),
-            // then the arithmetic.  A chain whose particles sit on dozens of private columns updates dozens of clusters per step.
+            // The owner wave updates the clusters its register cache holds and that are updated in place (it has to refresh mu, lambda and
+            // the first term anyway); every other chosen cluster -- uncached, or cloned -- is left to the statistics phase behind the
+            // next workgroup barrier, where all four waves share them (help_stats).  Four clusters at a time: table entries, then the
+            // statistics and prefix constants (all loads in flight together), then the arithmetic.
             auto sb = PM2_G(double, v.ar.sb());
             const bool on = lane < D && fl[lane];
             for (int e0 = 0; e0 < nd; e0 += 4) {
-                int cj[4], tj[4], nj[4], sj[4];
+                int cj[4], nj[4], sj[4];
+                bool mine[4];
                 double sgj[4], btj[4], gj[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    cj[j] = 0; tj[j] = 0; nj[j] = 0; sj[j] = NONE8;
-                    if (e0 + j < nd) { cj[j] = chosen(e0 + j); tj[j] = v.tgt_get(cj[j]); nj[j] = v.cn_get(tj[j]); sj[j] = v.slot_of(cj[j]); }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    sgj[j] = pf_sg; btj[j] = pf_bt; gj[j] = 0.0;
+                    cj[j] = 0; nj[j] = 0; sj[j] = NONE8; mine[j] = false;
                     if (e0 + j < nd) {
-                        if (e0 + j > 0 && lane < D) { sgj[j] = sb[((size_t)cj[j] * D + lane) * 2]; btj[j] = sb[((size_t)cj[j] * D + lane) * 2 + 1]; }
-                        if (sj[j] != NONE8 && tj[j] == cj[j] && lane == 0) gj[j] = PM2_G(const double, d.gtab)[nj[j]];
+                        cj[j] = chosen(e0 + j);
+                        sj[j] = v.slot_of(cj[j]);
+                        mine[j] = sj[j] != NONE8 && v.tgt_get(cj[j]) == cj[j];
+                        if (mine[j]) nj[j] = v.cn_get(cj[j]); else ndefer += 1;
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (e0 + j < nd) {
+                    sgj[j] = pf_sg; btj[j] = pf_bt; gj[j] = 0.0;
+                    if (mine[j]) {
+                        if (e0 + j > 0 && lane < D) { sgj[j] = sb[((size_t)cj[j] * D + lane) * 2]; btj[j] = sb[((size_t)cj[j] * D + lane) * 2 + 1]; }
+                        if (lane == 0) gj[j] = PM2_G(const double, d.gtab)[nj[j]];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (mine[j]) {
                         double sg = sgj[j], bt = btj[j];
-                        if (on) pmdi_arith::gauss_add_sb(x, nj[j], sg, bt);
-                        if (lane < D && (on || tj[j] != cj[j])) { sb[((size_t)tj[j] * D + lane) * 2] = sg; sb[((size_t)tj[j] * D + lane) * 2 + 1] = bt; }
-                        if (sj[j] != NONE8 && tj[j] == cj[j]) cache_fill(v, k, sj[j], sg, bt, nj[j], false, true, gj[j]);
+                        if (on) {
+                            pmdi_arith::gauss_add_sb(x, nj[j], sg, bt);
+                            sb[((size_t)cj[j] * D + lane) * 2] = sg; sb[((size_t)cj[j] * D + lane) * 2 + 1] = bt;
+                        }
+                        cache_fill(v, k, sj[j], sg, bt, nj[j], false, true, gj[j]);
                     }
                 }
             }
@@ -1234,6 +1245,7 @@ struct Sweep2 {
             long long *w_ = wk(k);
             w_[WK_EVAL] += dsc[DS_NNEED]; w_[WK_UPD] += nd; w_[WK_CLONE] += nclone; w_[WK_SPLITS] += ncol_new - ncol;
             dsc[DS_MAXID] = maxid + nclone; dsc[DS_NCLS] = nrep; dsc[DS_NCOL] = ncol_new; dsc[DS_NDX] = 0; dsc[DS_NCLONE] = nclone;
+            dsc[DS_ND] = ndefer ? nd : 0; dsc[DS_NDLOW] = nd_low;
             // the particles have something to follow when a column was split or written, or when the class slots move: not when the
             // step had one class, one (class, label) key and no clone (the key's class is slot 0 again)
             dsc[DS_FOLLOW] = (nclone != 0 || ncls != 1 || nk != 1) ? 1 : 0;
@@ -1244,6 +1256,67 @@ struct Sweep2 {
         }
         (void)pos;
         return true;
+    }
+
+    // ---- statistics phase (all waves, behind the barrier that ends the bookkeeping phase): deepcopy + cluster_add! (:297,:300) of the
+    //      chosen clusters the owner waves left -- every one that is not (cached and updated in place).  The batches of all
+    //      datasets are dealt round-robin to the four waves: a chain whose particles sit on dozens of private columns in ONE dataset
+    //      updates dozens of clusters per step there, and the waves of the quiet datasets would only wait for it.  Returns whether
+    //      there was anything to do (uniform): the caller then closes the phase with a workgroup barrier.
+    PM2_DEV bool help_stats(int i_cur)
+    {
+        constexpr int HB = 2;                  // clusters per batch (two: the phase runs with every lane's particle state live)
+        int item = 0;
+        bool any = false;
+#pragma nounroll
+        for (int k = 0; k < K; ++k) {
+            const DV v = view(k);
+            const int *dsc = v.dsc();
+            const int nd = PM2_UNI(dsc[DS_ND]);
+            if (nd == 0) continue;
+            any = true;
+            const int nd_low = PM2_UNI(dsc[DS_NDLOW]);
+            const auto &d = ap->ds[k];
+            const int D = d.D;
+            const u8 *fl = flk(k);
+            const bool on = lane < D && fl[lane];
+            const u16 *clist = lds<u16>(v.base + L.clist);
+            auto sb = PM2_G(double, v.ar.sb());
+            double x = 0.0;
+            bool have_x = false;
+            for (int e0 = 0; e0 < nd; e0 += HB, ++item) {
+                if ((item & 3) != wave) continue;
+                if (!have_x) { if (lane < D) x = PM2_G(const double, d.xf)[(size_t)i_cur * D + lane]; have_x = true; }
+                int cj[HB], tj[HB], nj[HB];
+                bool mine[HB];
+                double sgj[HB], btj[HB];
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    cj[j] = 0; tj[j] = 0; nj[j] = 0; mine[j] = false;
+                    if (e0 + j < nd) {
+                        const int e = e0 + j;
+                        cj[j] = (e < nd_low) ? (int)clist[e] : PM2_G(const int, v.ar.dl())[e - nd_low];
+                        tj[j] = v.tgt_get(cj[j]);
+                        mine[j] = !(v.slot_of(cj[j]) != NONE8 && tj[j] == cj[j]);
+                        if (mine[j]) nj[j] = v.cn_get(tj[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    sgj[j] = 0.0; btj[j] = 0.5;
+                    if (mine[j] && lane < D) { sgj[j] = sb[((size_t)cj[j] * D + lane) * 2]; btj[j] = sb[((size_t)cj[j] * D + lane) * 2 + 1]; }
+                }
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    if (mine[j]) {
+                        double sg = sgj[j], bt = btj[j];
+                        if (on) pmdi_arith::gauss_add_sb(x, nj[j], sg, bt);
+                        if (lane < D && (on || tj[j] != cj[j])) { sb[((size_t)tj[j] * D + lane) * 2] = sg; sb[((size_t)tj[j] * D + lane) * 2 + 1] = bt; }
+                    }
+                }
+            }
+        }
+        return any;
     }
 
     // ---- the census of a lane's draw (`mult` of its particles drew the same class, column and label; p the first of them),
@@ -1719,6 +1792,7 @@ struct Sweep2 {
             PM2_FRESH_VGPR(tid); PM2_FRESH_VGPR(lane);
             const double x = xnext;
             const int ns0_cur = ns0_next;
+            const int i_cur = i_next;
             if (pos + 1 < n) {
                 i_next = i_next2;
                 if (owner) {
@@ -1860,6 +1934,8 @@ struct Sweep2 {
             PHC(15);
             PH2(7);
             if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
+            // ---- statistics of the chosen clusters the owner waves left to everybody
+            if (help_stats(i_cur)) PM2_BARRIER();
             // ---- every particle follows its group: new column, new class slot
 #pragma nounroll
             for (int k = 0; k < K; ++k) {
