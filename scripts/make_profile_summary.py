@@ -23,6 +23,10 @@ FLT = os.environ.get("PMDI_KERNEL_FILTER", "")
 out = os.path.join("profiles", tag); os.makedirs(out, exist_ok=True)
 
 
+def is_sweep(name):
+    return "pmdi_sweep2_kernel" in name or ("pmdi_sweep_kernel" in name and FLT in name)
+
+
 def f1(d, *pats):
     for pat in pats:
         hits = glob.glob(os.path.join(d, "**", pat), recursive=True)
@@ -32,12 +36,12 @@ def f1(d, *pats):
 
 
 def sweep_sets(d):
-    rows = [r for r in csv.DictReader(open(f1(d, "*kernel_trace.csv"))) if "pmdi_sweep_kernel" in r["Kernel_Name"] and FLT in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(f1(d, "*kernel_trace.csv"))) if is_sweep(r["Kernel_Name"])]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     sets, cur = [], []
-    for r in rows:      # a new set starts when a launch begins after the running set has ended and > 2 ms after it began
-        a = int(r["Start_Timestamp"])
-        if cur and a > max(int(x["End_Timestamp"]) for x in cur) and a - int(cur[0]["Start_Timestamp"]) > 2_000_000:
+    for r in rows:      # a sweep launches every build at most once (round 3: heaviest / heavy / settled-chain kernel / re-run of the
+        # chains that kernel gave back, the last one behind the settled launch): a kernel name seen again opens the next set
+        if cur and any(x["Kernel_Name"] == r["Kernel_Name"] for x in cur):
             sets.append(cur); cur = []
         cur.append(r)
     if cur:
@@ -61,7 +65,7 @@ for s in sets[-steps:]:
 def counters(d):
     """{counter: mean over the timed sets of the sum over the set's dispatches}; under counter collection the launches of a
     set run one after the other, so sets are rebuilt from that pass's own kernel trace by dispatch order."""
-    rs = [r for r in csv.DictReader(open(f1(d, "*counter_collection.csv", "*counter_collection_trace.csv"))) if "pmdi_sweep_kernel" in r["Kernel_Name"] and FLT in r["Kernel_Name"]]
+    rs = [r for r in csv.DictReader(open(f1(d, "*counter_collection.csv", "*counter_collection_trace.csv"))) if is_sweep(r["Kernel_Name"])]
     per = {}
     for r in rs:
         per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
