@@ -49,7 +49,7 @@ DESCR = {
     "cfg5": "cfg5: 3 x Gaussian 20000x200, K=3, N=50, P=4096, rho=0.25, featureSelect on",
 }
 # chains per GPU (one workgroup each) and burn-in iterations per workload
-DEFAULTS = {"HL": (1024, 20), "cfg2": (2048, 30), "cfg3": (1024, 12), "cfg4": (256, 6), "cfg5": (256, 3)}
+DEFAULTS = {"HL": (1024, 20), "cfg2": (2048, 30), "cfg3": (1024, 12), "cfg4": (256, 6), "cfg5": (16, 3)}
 
 
 def algorithmic_bytes(w, P, n, n1, work, stats, layout="column"):

@@ -626,9 +626,11 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         // automatic width: split the chains of a sweep into a heavy and a light launch
         h->split = cfg->block_threads == 0 && (h->T > 256 || h->s2_ok) && env_int("PMDI_SPLIT", 1) != 0;
         if (!h->split) h->s2_ok = false;
-        // with the settled-chain kernel every chain is "light" until that kernel gives it back (it evaluates any number of live
-        // clusters in place, slower per step but still ahead of the general kernel); without it: few live clusters per step
-        h->light_ids = env_int("PMDI_LIGHT_IDS", h->s2_ok ? 1000000 : 40);
+        // A chain is "light" when its last sweep met few live clusters per step.  With the settled-chain kernel: as many as that kernel's
+        // LDS id tables hold (it evaluates any number in place -- HL's busiest chains, 40-90 ids per step, run 20 % faster there than
+        // in the general kernel -- but a K = 1 chain that never resamples keeps thousands of private clusters, and those steps belong to
+        // the general kernel's hash tables: cfg2 with every chain light took 3.4 s per sweep instead of 0.8).  Without it: 40.
+        h->light_ids = env_int("PMDI_LIGHT_IDS", h->s2_ok ? h->s2.idcap : 40);
         if (h->split) {
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
         }
