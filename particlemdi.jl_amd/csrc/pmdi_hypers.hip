@@ -487,12 +487,12 @@ __global__ void __launch_bounds__(256) align_kernel(const GibbsArgs a)
     double *rel = philog + 32;                      // [8]
     double *keep = rel + 8;                         // [8]
     double *swp = keep + 8;                         // [8]
-    double *gk = swp + 8;                           // [N <= 128]
-    int *firstpos = (int *)(gk + 128);              // [128]
-    int *occ = firstpos + 128;                      // [128]
-    int *perm = occ + 128;                          // [128]
-    int *lcount = perm + 128;                       // [128]
-    int *misc = lcount + 128;                       // [8]
+    double *gk = swp + 8;                           // [N <= 256]
+    int *firstpos = (int *)(gk + 256);              // [256]
+    int *occ = firstpos + 256;                      // [256]
+    int *perm = occ + 256;                          // [256]
+    int *lcount = perm + 256;                       // [256]
+    int *misc = lcount + 256;                       // [8]
     int *s = a.s + (size_t)chain * K * n;
     double *gG = a.gamma + (size_t)chain * K * N;
 
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(256) align_kernel(const GibbsArgs a)
     for (int k = 0; k < K; ++k) {
         int *sk = s + (size_t)k * n;
         // occupied = unique(s[:, k]): labels in order of first appearance over i = 1..n
-        if (tid < 128) { firstpos[tid] = PMDI_INF_I; lcount[tid] = 0; perm[tid] = tid; }
+        if (tid < 256) { firstpos[tid] = PMDI_INF_I; lcount[tid] = 0; perm[tid] = tid; }
         if (tid < N) gk[tid] = gG[k * N + tid];
         __syncthreads();
         for (long long i = tid; i < n; i += 256) { const int l = sk[i]; atomicMin(&firstpos[l], (int)i); atomicAdd(&lcount[l], 1); }
@@ -606,7 +606,7 @@ size_t pmdi_hypers_lds_bytes(const GibbsArgs &a)
 size_t pmdi_align_lds_bytes(const GibbsArgs &a)
 {
     const size_t tabsz = (size_t)a.K * a.K * a.N * a.N * 4;
-    return (a.ctab_lds ? ((tabsz + 15) & ~(size_t)15) : 0) + (32 + 8 + 8 + 8 + 128) * 8 + (128 * 4 + 8) * 4 + 64;
+    return (a.ctab_lds ? ((tabsz + 15) & ~(size_t)15) : 0) + (32 + 8 + 8 + 8 + 256) * 8 + (256 * 4 + 8) * 4 + 64;
 }
 
 hipError_t pmdi_launch_gibbs_init(const GibbsArgs &a, hipStream_t stream)

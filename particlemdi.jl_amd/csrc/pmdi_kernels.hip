@@ -247,7 +247,7 @@ hipError_t pmdi_launch_cluster_logmarginal(const ClusterBatchArgs &a, hipStream_
 // countn (src/misc.jl) for all labels of one (chain, dataset) row of allocations: LDS histogram
 __global__ void __launch_bounds__(256) label_count_kernel(const int *__restrict__ s, int *__restrict__ counts, long long n, int N)
 {
-    __shared__ int hist[128];  // N <= 128 (pmdi_create)
+    __shared__ int hist[256];  // N <= 255 (pmdi_create)
     const int row = blockIdx.x;
     for (int l = threadIdx.x; l < N; l += blockDim.x) hist[l] = 0;
     __syncthreads();

@@ -1563,13 +1563,17 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             PH(4); FRESH_LANE_IDS();
             const auto cdfp = dual(small, sh.cdf, s.cdf);
             if (N > 64) {
-                // 64 < N <= 128: one class per wave, the labels in two chunks of 64 lanes (same arithmetic, same order:
-                // c[n] = e[0] + (e[1] + ... + e[n]) is Julia's accumulate_pairwise! for fewer than 129 elements)
-                double *wv = gen(sh.term + wave * 256);      // v[0..127], e[0..127]
+                // 64 < N <= 255: one class per wave, the labels in up to four chunks of 64 lanes (same arithmetic, same order as Julia's
+                // accumulate_pairwise!: c[0] = e[0]; fewer than 128 further elements: c[n] = e[0] + (e[1] + ... + e[n]); else the rest
+                // splits once into two leaves (both shorter than 128 up to N = 255) and the right leaf's carry is e[0] + total(left))
+                constexpr int NC = 4;
+                double *wv = gen(sh.term + wave * 512);      // v[0..255], e[0..255]
+                const int nrest = N - 1;
+                const int n2 = (nrest >= 128) ? (nrest >> 1) : nrest;       // elements 1 .. n2 form the left (or only) leaf
                 for (int r = wave; r < ncls; r += T / 64) {
-                    double v2[2] = {0.0, 0.0};
+                    double v2[NC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < NC; ++c) {
                         const int nn = lane + 64 * c;
                         if (nn < N) {
                             if (small) v2[c] = sh.lpl[sh.h1.a[ht_find(sh.h1, sh.item_id[r * N + nn])]];
@@ -1581,60 +1585,62 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     __builtin_amdgcn_wave_barrier();
                     double m = wv[0];
                     for (int j = 1; j < N; ++j) { const double t = wv[j]; m = (t > m) ? t : m; }
-                    double e2[2] = {0.0, 0.0};
+                    double e2[NC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < NC; ++c) {
                         const int nn = lane + 64 * c;
                         if (nn < N) {
                             double e = v2[c] - m;
                             e = exp(e);
                             e = e * pik[nn];
                             e2[c] = e;
-                            wv[128 + nn] = e;
+                            wv[256 + nn] = e;
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    const double e0 = wv[128];
-                    double c2[2] = {0.0, 0.0};
+                    const double e0 = wv[256];
+                    double carry_r = e0;                       // carry of the right leaf (only when the rest was split)
+                    if (n2 < nrest) {
+                        double tl = wv[256 + 1];
+                        for (int j = 2; j <= n2; ++j) tl = tl + wv[256 + j];
+                        carry_r = e0 + tl;
+                    }
+                    double c2[NC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < NC; ++c) {
                         const int nn = lane + 64 * c;
                         if (nn < N) {
+                            const int j0 = (nn <= n2) ? 1 : n2 + 1;            // first element of the leaf that holds nn
                             double s_ = 0.0;
-                            for (int j = 1; j <= nn; ++j) { const double t = wv[128 + j]; s_ = (j == 1) ? t : s_ + t; }
-                            c2[c] = (nn == 0) ? e2[c] : e0 + s_;
+                            for (int j = j0; j <= nn; ++j) { const double t = wv[256 + j]; s_ = (j == j0) ? t : s_ + t; }
+                            c2[c] = (nn == 0) ? e2[c] : ((nn <= n2) ? e0 + s_ : carry_r + s_);
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) { const int nn = lane + 64 * c; if (nn < N) wv[nn] = c2[c]; }
+                    for (int c = 0; c < NC; ++c) { const int nn = lane + 64 * c; if (nn < N) wv[nn] = c2[c]; }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const double fN = wv[N - 1];
-                    unsigned long long mo[2], mt[2];
-                    double cd2[2];
+                    unsigned long long mo[NC], mt[NC];
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
+                    for (int c = 0; c < NC; ++c) {
                         const int nn = lane + 64 * c;
-                        cd2[c] = c2[c] / fN;
-                        mo[c] = __ballot(nn < N && (cd2[c] == 1.0 || nn == N - 1));
-                        mt[c] = __ballot(nn < N && cd2[c] < 0x1p-53);
-                        if (nn < N) cdfp[(size_t)r * (N + 2) + nn] = cd2[c];
+                        const double cd = c2[c] / fN;
+                        mo[c] = __ballot(nn < N && (cd == 1.0 || nn == N - 1));
+                        mt[c] = __ballot(nn < N && cd < 0x1p-53);
+                        if (nn < N) cdfp[(size_t)r * (N + 2) + nn] = cd;
                     }
                     if (lane == 0) {
                         cdfp[(size_t)r * (N + 2) + N] = log(fN) + m;
-                        const int nstar = mo[0] ? __ffsll((long long)mo[0]) - 1 : 64 + __ffsll((long long)mo[1]) - 1;
-                        bool onehot;
-                        if (nstar < 64) {
-                            const unsigned long long below = (nstar == 0) ? 0ull : ((1ull << nstar) - 1ull);
-                            onehot = (mt[0] & below) == below;
-                        } else {
-                            const int ns1 = nstar - 64;
-                            const unsigned long long below = (ns1 == 0) ? 0ull : ((1ull << ns1) - 1ull);
-                            onehot = mt[0] == ~0ull && (mt[1] & below) == below;
-                        }
-                        cdfp[(size_t)r * (N + 2) + N + 1] = onehot ? (double)nstar : -1.0;
+                        int cs = 0;
+                        while (cs < NC - 1 && mo[cs] == 0) ++cs;            // chunk of the first label whose CDF is 1
+                        const int ns1 = __ffsll((long long)mo[cs]) - 1;
+                        const unsigned long long below = (ns1 == 0) ? 0ull : ((1ull << ns1) - 1ull);
+                        bool onehot = (mt[cs] & below) == below;
+                        for (int c = 0; c < cs; ++c) onehot = onehot && mt[c] == ~0ull;
+                        cdfp[(size_t)r * (N + 2) + N + 1] = onehot ? (double)(64 * cs + ns1) : -1.0;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }

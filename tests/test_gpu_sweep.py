@@ -153,6 +153,16 @@ def test_edges(pkg, O, N, P, n1, n):
     _compare_run(pkg, O, [g, c], ["gaussian", "categorical"], N, P, 2, 70 + N, n1)
 
 
+@pytest.mark.parametrize("N,P,block", [(150, 256, 0), (192, 128, 0), (180, 512, 512)])
+def test_more_than_128_labels(pkg, O, N, P, block):
+    """N up to 192 (the reference: any N <= n; here two particle classes' items must fit the 384-entry LDS tables): beyond 128 labels the mutation CDF's cumsum
+    (src/pmdi.jl:240) is Base's pairwise one -- c[1] = e1, the other N - 1 elements split once into two leaves --, formed by one
+    wave with four labels per lane.  Mixed data types, two sweeps, everything equal to the oracle."""
+    rng = np.random.default_rng(12)
+    data, kinds = make_mixed(rng, 320)
+    _compare_run(pkg, O, data, kinds, N, P, 2, 40 + N, 60, block=block)
+
+
 def test_all_three_step_paths_are_exercised(pkg, O, monkeypatch):
     """The general kernel's fast (LDS tables), converted (LDS census overflow) and fallback (burn-in) steps all occur
     somewhere in this run, and the result is still the oracle's.  (PMDI_SETTLED=0: from the second sweep on the chain would

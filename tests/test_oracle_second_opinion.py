@@ -77,6 +77,15 @@ def test_more_particles_than_a_cumsum_block(O):
     assert tot["n_resamples"] > 0
 
 
+def test_more_labels_than_a_cumsum_block(O):
+    """N > 128 puts the mutation CDF's cumsum (src/pmdi.jl:240) on Base's pairwise path as well: c[1] = e1, the other N - 1 elements
+    split once into two leaves, the right leaf carried by e1 + total(left)."""
+    rng = np.random.default_rng(34)
+    z = rng.integers(0, 3, 170)
+    data = [rng.normal(size=(170, 3)) + 2.0 * z[:, None]]
+    _run_both(O, data, ["gaussian"], N=150, P=8, seed=3, iters=1, n1=20, rng=rng)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_small_configurations(O, seed):
     rng = np.random.default_rng(9000 + seed)
