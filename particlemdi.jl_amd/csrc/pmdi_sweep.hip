@@ -1634,12 +1634,17 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
                     }
                     if (lane == 0) {
                         cdfp[(size_t)r * (N + 2) + N] = log(fN) + m;
-                        int cs = 0;
-                        while (cs < NC - 1 && mo[cs] == 0) ++cs;            // chunk of the first label whose CDF is 1
-                        const int ns1 = __ffsll((long long)mo[cs]) - 1;
+                        // the first label whose CDF is 1 (chunk cs, bit ns1) and whether every label before it is negligible
+                        int cs = NC - 1;
+                        unsigned long long mo_s = mo[NC - 1], mt_s = mt[NC - 1];
+                        bool full_before = true;             // every label of the chunks before cs is negligible
+#pragma unroll
+                        for (int c = NC - 2; c >= 0; --c) if (mo[c] != 0) { cs = c; mo_s = mo[c]; mt_s = mt[c]; }
+#pragma unroll
+                        for (int c = 0; c < NC - 1; ++c) if (c < cs) full_before = full_before && mt[c] == ~0ull;
+                        const int ns1 = __ffsll((long long)mo_s) - 1;
                         const unsigned long long below = (ns1 == 0) ? 0ull : ((1ull << ns1) - 1ull);
-                        bool onehot = (mt[cs] & below) == below;
-                        for (int c = 0; c < cs; ++c) onehot = onehot && mt[c] == ~0ull;
+                        const bool onehot = full_before && (mt_s & below) == below;
                         cdfp[(size_t)r * (N + 2) + N + 1] = onehot ? (double)(64 * cs + ns1) : -1.0;
                     }
                     __builtin_amdgcn_wave_barrier();

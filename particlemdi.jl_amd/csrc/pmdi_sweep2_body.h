@@ -76,6 +76,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
 // address is passed through an empty asm: what is derived from it (array addresses of K datasets, LDS offsets) is then rebuilt
 // from scalar loads where it is used instead of being hoisted out of the sweep loop into registers that do not exist
 #define PM2_CONST __attribute__((address_space(4)))
+#ifdef PM2_NO_LAUNDER
+#define PM2_LAUNDER(ptr_, T) do { } while (0)
+#else
 #define PM2_LAUNDER(ptr_, T)                                                                                                      \
     do {                                                                                                                          \
         const unsigned long long v_ = (unsigned long long)(ptr_);                                                                 \
@@ -83,6 +86,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
         asm volatile("" : "+s"(lo_), "+s"(hi_));                                                                                  \
         (ptr_) = (const PM2_CONST T *)(((unsigned long long)hi_ << 32) | (unsigned long long)lo_);                               \
     } while (0)
+#endif
 #define PM2_FRESH_VGPR(x_) asm volatile("" : "+v"(x_))
 #else
 #define PM2_G(T, p) ((T *)(p))
