@@ -32,6 +32,8 @@ extern "C" {
 
 #define PMDI_ABI_VERSION 1
 #define PMDI_KMAX 8 /* datasets per handle */
+/* Other limits of this build (pmdi_create rejects what exceeds them with PMDI_E_ARG / PMDI_E_DATA): N <= 255 clusters (the reference:
+ * N <= n, src/pmdi.jl:54; labels travel as bytes), categorical levels <= 4096 per feature (host-built log tables), P <= 1048575. */
 
 /* dataTypes[k] of pmdi(): GaussianCluster (src/datatypes/gaussian_cluster.jl),
  * CategoricalCluster (categorical_cluster.jl), NegBinomCluster (negbinom_cluster.jl) */

@@ -412,7 +412,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if (K < 1 || K > PMDI_KMAX_I) return fail(PMDI_E_ARG, "K=%d outside 1..%d", K, PMDI_KMAX_I);
     if (n < 2 || n > 0x7fffffffLL / 4) return fail(PMDI_E_ARG, "n=%lld out of range", n);
     if (!(N <= n && N > 1)) return fail(PMDI_E_ARG, "Number of clusters must be greater than 1 and not greater than the number of observations");
-    if (N > 192) return fail(PMDI_E_ARG, "N=%d: this build supports N <= 192 (the (class, label) item tables of a step hold 384 entries and two classes must fit; the mutation CDF of a particle class is formed by one wave, up to four labels per lane, pairwise beyond 128 like Base.cumsum)", N);
+    if (N > 255) return fail(PMDI_E_ARG, "N=%d: this build supports N <= 255 (labels travel as bytes; the mutation CDF of a particle class is formed by one wave, up to four labels per lane, pairwise beyond 128 like Base.cumsum)", N);
     if (P < 2) return fail(PMDI_E_ARG, "Conditional particle filter requires 2 or more particles");
     if (P > 1048575) return fail(PMDI_E_ARG, "P=%d too large", P);
     if (cfg->n_chains < 1) return fail(PMDI_E_ARG, "n_chains must be >= 1");
@@ -520,7 +520,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     if (h->T != 128 && h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 128, 256, 512 or 1024"));
     {
         auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
-        if (2 * N > (N > 32 ? PMDI_ITEM_CAP_BIGN : PMDI_ITEM_CAP)) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables (two particle classes' (class, label) items must fit them: N <= 192)", N));
+        // (a step whose particle classes' (class, label) items outgrow the LDS tables takes the general route through global memory;
+        // one class always fits: N <= 255 < 384)
+        if (N > (N > 32 ? PMDI_ITEM_CAP_BIGN : PMDI_ITEM_CAP)) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));
         // K > 1: one workgroup per (chain, dataset), meeting once per swept observation (pmdi_sweep.hip): 2.2x shorter sweeps per
         // chain, but the partners repeat the per-observation serial work (weights, ESS, resampling indices), so when the chains alone
         // can fill the GPU the single-workgroup form has the higher aggregate throughput.  Default: split while every workgroup of

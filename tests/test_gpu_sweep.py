@@ -153,9 +153,9 @@ def test_edges(pkg, O, N, P, n1, n):
     _compare_run(pkg, O, [g, c], ["gaussian", "categorical"], N, P, 2, 70 + N, n1)
 
 
-@pytest.mark.parametrize("N,P,block", [(150, 256, 0), (192, 128, 0), (180, 512, 512)])
+@pytest.mark.parametrize("N,P,block", [(129, 64, 0), (150, 256, 0), (200, 128, 0), (255, 256, 0), (180, 512, 512)])
 def test_more_than_128_labels(pkg, O, N, P, block):
-    """N up to 192 (the reference: any N <= n; here two particle classes' items must fit the 384-entry LDS tables): beyond 128 labels the mutation CDF's cumsum
+    """N up to 255 (the reference: any N <= n; labels travel as bytes here): beyond 128 labels the mutation CDF's cumsum
     (src/pmdi.jl:240) is Base's pairwise one -- c[1] = e1, the other N - 1 elements split once into two leaves --, formed by one
     wave with four labels per lane.  Mixed data types, two sweeps, everything equal to the oracle."""
     rng = np.random.default_rng(12)
