@@ -1358,7 +1358,8 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
 // at T = 512 need 4)
 // K1: single-dataset models (K == 1) get a specialisation in which the dataset index is a
 // compile-time 0, so the per-dataset views are loop invariants of the sweep loop.
-template <int T, int WPS, bool K1>
+// MANY: the build for more than 64 labels (its CDF stage holds four labels per lane: registers every other build would pay for)
+template <int T, int WPS, bool K1, bool MANY>
 __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__restrict__ ap)
 {
     PMDI_PREAMBLE_K(K1);
@@ -1562,7 +1563,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             // accumulate_pairwise!: c[n] = e[0] + (e[1] + ... + e[n]).
             PH(4); FRESH_LANE_IDS();
             const auto cdfp = dual(small, sh.cdf, s.cdf);
-            if (N > 64) {
+            if (MANY && N > 64) {
                 // 64 < N <= 255: one class per wave, the labels in up to four chunks of 64 lanes (same arithmetic, same order as Julia's
                 // accumulate_pairwise!: c[0] = e[0]; fewer than 128 further elements: c[n] = e[0] + (e[1] + ... + e[n]); else the rest
                 // splits once into two leaves (both shorter than 128 up to N = 255) and the right leaf's carry is e[0] + total(left))
@@ -2233,11 +2234,15 @@ static const void *sweep_kernel_for(const SweepArgs &a, int T)
 {
     const bool two = a.two_per_cu != 0;
     const bool k1 = a.K == 1 || a.ksplit;      // one dataset per workgroup
-    if (T == 1024) return k1 ? (const void *)pmdi_sweep_kernel<1024, 4, true> : (const void *)pmdi_sweep_kernel<1024, 4, false>;
-    if (T == 512 && two) return k1 ? (const void *)pmdi_sweep_kernel<512, 4, true> : (const void *)pmdi_sweep_kernel<512, 4, false>;
-    if (T == 512) return k1 ? (const void *)pmdi_sweep_kernel<512, 2, true> : (const void *)pmdi_sweep_kernel<512, 2, false>;
-    if (T == 128) return k1 ? (const void *)pmdi_sweep_kernel<128, 2, true> : (const void *)pmdi_sweep_kernel<128, 2, false>;
-    if (T == 256) return k1 ? (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, true> : (const void *)pmdi_sweep_kernel<256, PMDI_LIGHT_WPS, false>;
+    const bool many = a.N > 64;
+#define PMDI_PICK(T_, W_) (k1 ? (many ? (const void *)pmdi_sweep_kernel<T_, W_, true, true> : (const void *)pmdi_sweep_kernel<T_, W_, true, false>) \
+                              : (many ? (const void *)pmdi_sweep_kernel<T_, W_, false, true> : (const void *)pmdi_sweep_kernel<T_, W_, false, false>))
+    if (T == 1024) return PMDI_PICK(1024, 4);
+    if (T == 512 && two) return PMDI_PICK(512, 4);
+    if (T == 512) return PMDI_PICK(512, 2);
+    if (T == 128) return PMDI_PICK(128, 2);
+    if (T == 256) return PMDI_PICK(256, PMDI_LIGHT_WPS);
+#undef PMDI_PICK
     return nullptr;
 }
 

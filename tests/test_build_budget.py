@@ -16,9 +16,11 @@ BUDGET = {            # (T, WPS, K1) -> max VGPR spill slots as `-Rpass-analysis
     # measured 166 / 75 / 13 (round 2: 203 / 46 / 29; HL +7.8 % on the GPU, the 256-register wide build pays for it).  The light
     # build is at the <= 16 the round-2 review asked for; settled chains no longer run on these builds at all when the settled-chain
     # kernel (pmdi_sweep2.hip) takes them.
-    "ILi512ELi4ELb1": 170,
-    "ILi512ELi2ELb1": 80,
-    "ILi256ELi2ELb1": 16,
+    # (the last flag: the build for more than 64 labels, whose CDF stage holds four labels per lane -- 200 / 85 / 39 slots; every
+    # handle with N <= 64 gets the builds below, which no longer carry that code at all: 177 / 43 / 12)
+    "ILi512ELi4ELb1ELb0": 180,
+    "ILi512ELi2ELb1ELb0": 80,
+    "ILi256ELi2ELb1ELb0": 16,
 }
 
 
