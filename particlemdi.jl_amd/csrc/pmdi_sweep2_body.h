@@ -1876,19 +1876,32 @@ struct Sweep2 {
                         packed = 0;
                     }
                 }
+                PHD(8);
+                {
+                    // particles of the lane that drew the same class, column and label are counted with the first of them; when that is all
+                    // of them in every lane of the wave (the rule between resampling events), one call does it
+                    int keyu[PPL];
 #pragma unroll
-                for (int u = 0; u < PPL; ++u) {
-                    PHD(8);
-                    // particles of the lane that drew the same class, column and label are counted with the first of them
-                    bool dup = false;
-                    int mult = 0;
+                    for (int u = 0; u < PPL; ++u) keyu[u] = (r_[u] * P + cl_[u]) * N + nsv[u];
+                    bool allsame = true;
 #pragma unroll
-                    for (int u2 = 0; u2 < PPL; ++u2) {
-                        const bool same = r_[u2] == r_[u] && cl_[u2] == cl_[u] && nsv[u2] == nsv[u];
-                        if (u2 < u) dup |= same;
-                        if (u2 >= u) mult += same ? 1 : 0;
+                    for (int u = 1; u < PPL; ++u) allsame = allsame && keyu[u] == keyu[0];
+                    if (PM2_BALLOT(!allsame) == 0) {
+                        census(v, true, PPL, r_[0], cl_[0], nsv[0], c_[0], tid * PPL);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < PPL; ++u) {
+                            bool dup = false;
+                            int mult = 0;
+#pragma unroll
+                            for (int u2 = 0; u2 < PPL; ++u2) {
+                                const bool same = keyu[u2] == keyu[u];
+                                if (u2 < u) dup |= same;
+                                if (u2 >= u) mult += same ? 1 : 0;
+                            }
+                            census(v, !dup, mult, r_[u], cl_[u], nsv[u], c_[u], tid * PPL + u);
+                        }
                     }
-                    census(v, !dup, mult, r_[u], cl_[u], nsv[u], c_[u], tid * PPL + u);
                 }
             }
             PHD(9);
