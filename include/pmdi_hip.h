@@ -96,7 +96,13 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
 
 /* Tuning knobs read from the environment at pmdi_create (results never depend on them):
  *   PMDI_SPLIT=0          one launch per sweep instead of the heaviest / heavy / light launches (block_threads = 0)
- *   PMDI_LIGHT_IDS=40     a chain whose last sweep met at most this many live clusters per step is "light"
+ *   PMDI_LIGHT_IDS        a chain whose last sweep met at most this many live clusters per step is "light" (default: the LDS id
+ *                         capacity of the settled-chain kernel, 128, where the handle has that kernel; else 40)
+ *   PMDI_SETTLED=0/2      never / from the first sweep on use the settled-chain kernel (default: all-Gaussian handles with
+ *                         2 <= K <= 4, N <= 64, D <= 64, P in {256, 512, 1024}, after a chain's first sweep; pmdi_settled_kernel())
+ *   PMDI_S2_COLS=64, PMDI_S2_IDCAP=128   columns / cluster ids its LDS tables hold before they continue in the arena (shrunk by
+ *                         pmdi_create until two workgroups fit a CU)
+ *   PMDI_REQUEUE_KSPLIT=0 re-run the chains that kernel gives back in one workgroup instead of K
  *   PMDI_VERY_HEAVY=128   how many of the heaviest chains get a CU each
  *   PMDI_HEAVY_T          workgroup width of the heavy group (512 or 1024)
  *   PMDI_TWO_PER_CU=0     256-register builds everywhere (one wide chain per CU)
