@@ -48,8 +48,10 @@ DESCR = {
     "cfg4": "cfg4: 2 x Gaussian 10000x50 + Categorical 10000x20 + NegBinom 10000x30, K=4, N=50, P=2048, rho=0.25",
     "cfg5": "cfg5: 3 x Gaussian 20000x200, K=3, N=50, P=4096, rho=0.25, featureSelect on",
 }
-# chains per GPU (one workgroup each) and burn-in iterations per workload
-DEFAULTS = {"HL": (1024, 20), "cfg2": (2048, 30), "cfg3": (1024, 12), "cfg4": (256, 6), "cfg5": (16, 3)}
+# chains per GPU (one workgroup each) and burn-in iterations per workload.  HL: 2 048 chains since round 3 (227 GB of the 288 GB: the
+# arena of a chain is sized for N * P + 1 cluster ids) -- 512 workgroup slots, so four rounds of chains instead of two pack under the
+# slowest chain: 1 146 it/s against 1 001-1 009 with 1 024 chains (profiles/README.md r03 keeps both operating points)
+DEFAULTS = {"HL": (2048, 20), "cfg2": (2048, 30), "cfg3": (1024, 12), "cfg4": (256, 6), "cfg5": (16, 3)}
 
 
 def algorithmic_bytes(w, P, n, n1, work, stats, layout="column"):
