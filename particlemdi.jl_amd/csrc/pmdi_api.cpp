@@ -159,6 +159,7 @@ struct pmdi_handle {
     bool s2_ok = false;
     S2Layout s2{};
     int sweep_no = 0;
+    int sticky = 3;              // sweeps a chain stays with the general kernel after the settled-chain kernel gave it back (PMDI_STICKY)
     int err_keep = 0;            // set by the device-resident driver around its sweeps (pmdi_gibbs_step)
     int children = 0;            // live pmdi_gibbs / cluster-batch objects: pmdi_destroy refuses while > 0
     // feature selection
@@ -362,7 +363,7 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
         const long long steps = (a.n - a.n1 + 1) * (long long)a.K;
         e = pmdi_launch_chain_order((const long long *)h->d_cost.p, (int *)h->d_lorder.p, a.stats,
                                     h->split ? (unsigned char *)h->d_group.p : nullptr, h->light_ids * steps, C, st,
-                                    h->s2_ok ? (const int *)h->d_handed.p : nullptr, h->sweep_no);
+                                    h->s2_ok ? (const int *)h->d_handed.p : nullptr, h->sweep_no + 3 - h->sticky);
         if (e != hipSuccess) return fail(PMDI_E_DEVICE, "chain-order launch: %s", hipGetErrorString(e));
         h->have_order = true;
     }
@@ -635,6 +636,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         // in the general kernel -- but a K = 1 chain that never resamples keeps thousands of private clusters, and those steps belong to
         // the general kernel's hash tables: cfg2 with every chain light took 3.4 s per sweep instead of 0.8).  Without it: 40.
         h->light_ids = env_int("PMDI_LIGHT_IDS", h->s2_ok ? h->s2.idcap : 40);
+        h->sticky = env_int("PMDI_STICKY", 3);
         if (h->split) {
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
         }
