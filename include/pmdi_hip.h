@@ -104,7 +104,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
  *                         pmdi_create until two workgroups fit a CU)
  *   PMDI_REQUEUE_KSPLIT=0 re-run the chains that kernel gives back in one workgroup instead of K
  *   PMDI_STICKY=3         sweeps a given-back chain stays with the general kernel (HL, 2 048 chains: 0 -> 1 163, 3 -> 1 164, 10 -> 1 130 it/s)
- *   PMDI_VERY_HEAVY=128   how many of the heaviest chains get a CU each
+ *   PMDI_VERY_HEAVY=128   how many of the heaviest chains get a CU each (default 0 on handles with the settled-chain kernel)
  *   PMDI_HEAVY_T          workgroup width of the heavy group (512 or 1024)
  *   PMDI_TWO_PER_CU=0     256-register builds everywhere (one wide chain per CU)
  *   PMDI_TERMS_CAP        LDS doubles for the per-feature terms

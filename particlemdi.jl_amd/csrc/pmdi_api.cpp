@@ -651,7 +651,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 hipStreamCreateWithPriority(&h->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming) != hipSuccess)
                 return bail(fail(PMDI_E_DEVICE, "stream/event creation failed"));
-            h->very_heavy = (h->T == 512 && h->two_per_cu) ? env_int("PMDI_VERY_HEAVY", 128) : 0;
+            // (with the settled-chain kernel only the few chains it gave back lately are heavy at all: no CU-each launch for them --
+            // HL 1 160 it/s without against 1 146 with it -- and so no start gate either, which a profiler would switch off)
+            h->very_heavy = (h->T == 512 && h->two_per_cu) ? env_int("PMDI_VERY_HEAVY", h->s2_ok ? 0 : 128) : 0;
             int can_wait = 0;
             (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, cfg->device);
             // (not under a profiler that collects counters: rocprofv3 --pmc runs the kernels of all queues one at a time, and a launch
