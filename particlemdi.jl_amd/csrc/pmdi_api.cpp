@@ -604,27 +604,28 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 }
             }
         }
-        // the settled-chain kernel: all-Gaussian configurations of the shapes it is built for, the reference's default quirk modes,
-        // one workgroup per chain; its LDS tables sized so that two chains share a CU (fewer LDS columns / ids if need be)
+        // the settled-chain kernel: configurations of the shapes it is built for (any mix of the three cluster types), the reference's
+        // default quirk modes, one workgroup per chain; its LDS tables sized so that two 256-thread chains share a CU (fewer LDS columns /
+        // ids if need be); a 512-thread chain (P = 2 048) has a CU's registers to itself and may take its LDS too
         {
             // (K = 1: three of its four waves would idle through the cluster phases -- cfg2 runs 2 812 it/s on the general kernel's
             // one-dataset build and 2 086 with this kernel; PMDI_SETTLED=2 forces it for the tests of its K = 1 instantiations)
             bool ok = env_int("PMDI_SETTLED", 1) != 0 && (K >= 2 || env_int("PMDI_SETTLED", 1) == 2) && cfg->block_threads == 0 && !h->ksplit && cfg->q1_mode == 0 && cfg->q2_mode == 0 &&
                       pmdi_sweep2_supports(K, N, P, h->Dmax, cap);
-            for (int k = 0; k < K && ok; ++k) ok = h->ds[k].kind == K_GAUSSIAN;
             if (ok) {
+                const size_t budget = pmdi_sweep2_threads(K, P) > 256 ? (size_t)159 * 1024 : (size_t)80 * 1024;
                 int cols_l = env_int("PMDI_S2_COLS", 64), idcap = env_int("PMDI_S2_IDCAP", 128);
                 if (cols_l < 1) cols_l = 1;
                 if (cols_l > P) cols_l = P;
                 if (idcap < 8) idcap = 8;
                 if (idcap > 4096) idcap = 4096;
                 pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
-                while (h->s2.total > 80 * 1024 && (cols_l > 16 || idcap > 64)) {
+                while ((size_t)h->s2.total > budget && (cols_l > 16 || idcap > 64)) {
                     // (a settled chain holds 6-40 columns and ids below ~40 at the 99th percentile of its steps: the id tables go first)
                     if (idcap > 96) idcap -= 16; else if (cols_l > 32) cols_l -= 8; else if (idcap > 64) idcap -= 16; else cols_l -= 8;
                     pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
                 }
-                ok = h->s2.total <= 80 * 1024;
+                ok = (size_t)h->s2.total <= budget;
             }
             h->s2_ok = ok;
         }

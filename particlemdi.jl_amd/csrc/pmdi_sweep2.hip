@@ -5,36 +5,41 @@
 
 namespace {
 
-// Two workgroups per CU: 256 threads = one wave per SIMD each, so a SIMD hosts two waves and each may use up to 256 VGPRs.  The
-// particle state and the cluster cache of a wave live in registers for the whole sweep; nothing is spilled (tests/test_build_budget.py).
-template <int K, int PPL>
-__global__ void __launch_bounds__(256, 2) pmdi_sweep2_kernel(const SweepArgs *__restrict__ ap)
+// Two waves per SIMD whatever the workgroup's width (64 * NW threads: two 256-thread workgroups per CU, or one of 512) -- the second
+// launch bound is hipcc's waves-per-SIMD floor -- so a wave may use up to 256 VGPRs.  The particle state and the cluster cache of a wave live in registers for the whole sweep; the builds' spill
+// counts are pinned by tests/test_build_budget.py.
+template <int K, int PPL, int NW>
+__global__ void __launch_bounds__(64 * NW, 2) pmdi_sweep2_kernel(const SweepArgs *__restrict__ ap)
 {
     const SweepArgs &a = *ap;
     const int bslot = (int)blockIdx.x;
     const int chain = a.chain_order ? a.chain_order[bslot] : bslot;
     // the chains of a sweep are shared out between launches by what their previous sweep looked like (pmdi_api.cpp)
     if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || bslot < a.rank_lo || bslot >= a.rank_hi)) return;
-    pmdi_s2::Sweep2<K, PPL> s;
+    pmdi_s2::Sweep2<K, PPL, NW> s;
     s.run(ap, chain);
 }
 
+// the instantiations: P = 256 / 512 / 1024 particles on four waves (1, 2, 4 particles per lane), P = 2048 on eight waves (4 per lane)
 template <int K>
-const void *kernel_for_ppl(int ppl)
+const void *kernel_for_k(int P, int *nw)
 {
-    if (ppl == 1) return (const void *)pmdi_sweep2_kernel<K, 1>;
-    if (ppl == 2) return (const void *)pmdi_sweep2_kernel<K, 2>;
-    if (ppl == 4) return (const void *)pmdi_sweep2_kernel<K, 4>;
+    *nw = 4;
+    if (P == 256) return (const void *)pmdi_sweep2_kernel<K, 1, 4>;
+    if (P == 512) return (const void *)pmdi_sweep2_kernel<K, 2, 4>;
+    if (P == 1024) return (const void *)pmdi_sweep2_kernel<K, 4, 4>;
+    *nw = 8;
+    if (P == 2048) return (const void *)pmdi_sweep2_kernel<K, 4, 8>;
     return nullptr;
 }
 
-const void *kernel_for(int K, int ppl)
+const void *kernel_for(int K, int P, int *nw)
 {
     switch (K) {
-    case 1: return kernel_for_ppl<1>(ppl);
-    case 2: return kernel_for_ppl<2>(ppl);
-    case 3: return kernel_for_ppl<3>(ppl);
-    case 4: return kernel_for_ppl<4>(ppl);
+    case 1: return kernel_for_k<1>(P, nw);
+    case 2: return kernel_for_k<2>(P, nw);
+    case 3: return kernel_for_k<3>(P, nw);
+    case 4: return kernel_for_k<4>(P, nw);
     }
     return nullptr;
 }
@@ -46,26 +51,36 @@ void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, S2
     pmdi_s2::make_layout(K, N, P, Dmax, cols_l, idcap, *L);
 }
 
+int pmdi_sweep2_threads(int K, int P)
+{
+    int nw = 0;
+    return kernel_for(K, P, &nw) ? 64 * nw : 0;
+}
+
 // shapes the kernel is built for (the rest stays with pmdi_sweep.hip)
 bool pmdi_sweep2_supports(int K, int N, int P, int Dmax, long long cap)
 {
-    return K >= 1 && K <= pmdi_s2::KMAX2 && N >= 2 && N <= 64 && Dmax <= 64 && (P == 256 || P == 512 || P == 1024) && cap <= 65535;
+    (void)cap;      // (cluster ids travel as 16-bit values in the LDS tables: a chain whose ids would outgrow them is given back, pmdi_sweep2_body.h)
+    int nw;
+    return K >= 1 && K <= pmdi_s2::KMAX2 && N >= 2 && N <= 64 && Dmax <= 64 && kernel_for(K, P, &nw) != nullptr;
 }
 
 hipError_t pmdi_sweep2_blocks_per_cu(const SweepArgs &a, int *blocks)
 {
-    const void *fn = kernel_for(a.K, a.P / 256);
+    int nw = 0;
+    const void *fn = kernel_for(a.K, a.P, &nw);
     if (!fn) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.s2.total);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fn, 256, (size_t)a.s2.total);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fn, 64 * nw, (size_t)a.s2.total);
 }
 
 hipError_t pmdi_launch_sweep2(const SweepArgs &a_in, SweepArgs *d_args, int n_chains, hipStream_t stream, SweepArgs *staging)
 {
     SweepArgs a = a_in;
     a.n_slots = n_chains;
-    const void *fn = kernel_for(a.K, a.P / 256);
+    int nw = 0;
+    const void *fn = kernel_for(a.K, a.P, &nw);
     if (!fn) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.s2.total);
     if (e != hipSuccess) return e;
@@ -75,7 +90,7 @@ hipError_t pmdi_launch_sweep2(const SweepArgs &a_in, SweepArgs *d_args, int n_ch
     if (e != hipSuccess) return e;
     const SweepArgs *ap = d_args;
     void *args[] = {(void *)&ap};
-    e = hipLaunchKernel(fn, dim3((unsigned)n_chains), dim3(256), args, (size_t)a.s2.total, stream);
+    e = hipLaunchKernel(fn, dim3((unsigned)n_chains), dim3(64u * (unsigned)nw), args, (size_t)a.s2.total, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

@@ -26,33 +26,9 @@
 #include "pmdi_arith.h"
 #include "pmdi_internal.h"
 
-#ifdef PM2_EMU
-#include "../../tests/emu/wavesim.h"
-#include <math.h>
-#define PM2_DEV inline
-#define PM2_HD inline
-#define PM2_SMEM (wavesim::lds_base())
-#define PM2_TID() (wavesim::tid())
-#define PM2_BID() (wavesim::bid())
-#define PM2_BALLOT(p) wavesim::ballot((p), __LINE__)
-#define PM2_SHFL64(v, src) wavesim::shfl64((v), (src), __LINE__)
-#define PM2_WAVE_BARRIER() wavesim::wave_barrier(__LINE__)
-#define PM2_BARRIER() wavesim::block_barrier(__LINE__)
-#define PM2_LDS_BARRIER() wavesim::block_barrier(__LINE__)
-#define PM2_UNI(x) (x)
-#define PM2_CLOCK() (0ll)
-#define PM2_WALLCLOCK() (0ll)
-#define PM2_G(T, p) ((T *)(p))
-#define PM2_CONST
-#define PM2_LAUNDER(ptr_, T) do { } while (0)
-#define PM2_FRESH_VGPR(x_) do { } while (0)
-template <class T> inline T pm2_atomic_add(T *p, T v) { const T o = *p; *p = o + v; return o; }
-template <class T> inline T pm2_atomic_min(T *p, T v) { const T o = *p; if (v < o) *p = v; return o; }
-template <class T> inline T pm2_atomic_or(T *p, T v) { const T o = *p; *p = o | v; return o; }
-template <class T> inline T pm2_atomic_max(T *p, T v) { const T o = *p; if (v > o) *p = v; return o; }
-inline int pm2_popc64(unsigned long long x) { return __builtin_popcountll(x); }
-inline int pm2_ffs64(unsigned long long x) { return __builtin_ffsll((long long)x); }
-#else
+// The lane API of this file for gfx950.  (A translation unit that defines PM2_LANE_API_PROVIDED before including this header brings
+// its own: that is how the test suite runs this source on a CPU, see tests/emu/.  The product build never does.)
+#ifndef PM2_LANE_API_PROVIDED
 #define PM2_DEV __device__ __forceinline__
 #define PM2_HD inline __host__ __device__
 extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
@@ -105,7 +81,86 @@ template <class T> __device__ __forceinline__ T pm2_atomic_or(T *p, T v) { retur
 template <class T> __device__ __forceinline__ T pm2_atomic_max(T *p, T v) { return atomicMax(p, v); }
 __device__ __forceinline__ int pm2_popc64(unsigned long long x) { return __popcll(x); }
 __device__ __forceinline__ int pm2_ffs64(unsigned long long x) { return __ffsll((long long)x); }
-#endif
+
+namespace pmdi_s2 {
+typedef unsigned long long u64;
+PM2_DEV double shfl_d(double v, int src)
+{
+    union { double d; u64 u; } a, b;
+    a.d = v;
+    b.u = PM2_SHFL64(a.u, src);
+    return b.d;
+}
+PM2_DEV int shfl_i(int v, int src) { return (int)(unsigned)PM2_SHFL64((u64)(unsigned)v, src); }
+// the value of lane `src` (wave-uniform): v_readlane, no LDS round trip
+PM2_DEV int readlane_i(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
+PM2_DEV u64 readlane_u64(u64 v, int src)
+{
+    const int s_ = __builtin_amdgcn_readfirstlane(src);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, s_), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), s_);
+    return ((u64)hi << 32) | (u64)lo;
+}
+// wave-level reductions of a double on the DPP network: xor-1 and xor-2 inside quads, half-row and row mirrors give every lane its
+// 16-lane row total; the four row totals are read with v_readlane.  All 64 lanes must be active.
+template <int CTRL> PM2_DEV double dpp_d(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+PM2_DEV double readlane_d(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+PM2_DEV double wave_sum_d(double v)
+{
+    v += dpp_d<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_d<0x141>(v);     // row_half_mirror
+    v += dpp_d<0x140>(v);     // row_mirror
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
+PM2_DEV double wave_max_d(double v)
+{
+    double t;
+    t = dpp_d<0xB1>(v); v = (t > v) ? t : v;
+    t = dpp_d<0x4E>(v); v = (t > v) ? t : v;
+    t = dpp_d<0x141>(v); v = (t > v) ? t : v;
+    t = dpp_d<0x140>(v); v = (t > v) ? t : v;
+    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+    const double m01 = (r1 > r0) ? r1 : r0, m23 = (r3 > r2) ? r3 : r2;
+    return (m23 > m01) ? m23 : m01;
+}
+// the value of the lane below (lane 0 keeps its own): one DPP shift across the whole wave, no LDS round trip
+PM2_DEV double prev_lane_d(double v) { return dpp_d<0x138>(v); }      // wave_shr:1
+PM2_DEV double wave_min_d(double v)
+{
+    double t;
+    t = dpp_d<0xB1>(v); v = (t < v) ? t : v;
+    t = dpp_d<0x4E>(v); v = (t < v) ? t : v;
+    t = dpp_d<0x141>(v); v = (t < v) ? t : v;
+    t = dpp_d<0x140>(v); v = (t < v) ? t : v;
+    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+    const double m01 = (r1 < r0) ? r1 : r0, m23 = (r3 < r2) ? r3 : r2;
+    return (m23 < m01) ? m23 : m01;
+}
+// exclusive prefix sum of an int over the wave, and the total (the DPP network: shifts inside the rows of sixteen lanes, then the
+// row totals broadcast into the rows above; all lanes active)
+PM2_DEV int wave_excl_scan_i(int v, int &total)
+{
+    int inc = v;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);      // row_shr:1
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);      // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);      // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);      // row_shr:8
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    total = __builtin_amdgcn_readlane(inc, 63);
+    return inc - v;
+}
+}  // namespace pmdi_s2
+#endif  // PM2_LANE_API_PROVIDED
 
 namespace pmdi_s2 {
 
@@ -145,7 +200,7 @@ typedef unsigned long long u64;
 typedef unsigned short u16;
 typedef unsigned char u8;
 
-constexpr int T = 256;          // threads of the workgroup (4 waves)
+constexpr int NWMAX = 8;        // waves of a workgroup at most (the workgroup has NW of them: a template parameter of the sweep)
 constexpr int NS = 8;           // cluster cache slots per dataset (registers of the owner wave)
 constexpr int XR = 4;           // uncached clusters evaluated per round (their two term rows each borrow the cached clusters' tb rows)
 #ifndef PM2_XCAP
@@ -156,6 +211,8 @@ constexpr int NR = NS;          // term rows per dataset
 constexpr int CLS = 16;         // particle classes per dataset at most (beyond: requeue)
 constexpr int CSB = 4;          // bits of a class slot in the per-lane register word
 constexpr int RI_CLSMIN = 64, RI_NEWSLOT = 80, RI_CLSVAL = 96;      // resampling: per-class scratch, int offsets into the reduction area
+constexpr int RI_WCNT = 112;                                         // ... and per-wave counts of the block scans (NWMAX ints)
+constexpr int RD_MAX = 0, RD_MIN = NWMAX, RD_SA = 2 * NWMAX, RD_SQ = 3 * NWMAX;      // doubles of the reduction area: per-wave maxima, minima, sums
 constexpr int KMAX2 = 4;        // datasets (one owner wave each)
 constexpr int NONE8 = 0xFF;
 constexpr unsigned INFU = 0xFFFFFFFFu;
@@ -174,7 +231,7 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     auto take = [&](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };
     const int Dp = (Dmax + 1) & ~1;
     L.Dp = Dp; L.cols_l = cols_l; L.idcap = idcap;
-    L.red = take(128 * 8);       // reductions: [0,8) maxima, [8,16) sums, [16,32) integer scratch, [64,112) replay stacks, [120] tie
+    L.red = take(128 * 8);       // reductions: doubles [0,32) per-wave maxima / minima / sums (RD_*), ints [64,120) resampling scratch (RI_*), doubles [120] tie, [121] carry
     L.sc = take(SC_COUNT * 4);
     L.stat = take(8 * 8);
     L.wk = take(KMAX2 * 8 * 8);
@@ -237,6 +294,8 @@ struct Arena {   // the chain's arrays of one dataset in global memory (what exc
     PM2_DEV int *firstp() const { return (int *)(b + d->o_firstc); }
     PM2_DEV int *tgt() const { return (int *)(b + d->o_lp); }
     PM2_DEV double *sb() const { return (double *)(b + d->o_sb); }
+    PM2_DEV int *cnt() const { return (int *)(b + d->o_cnt); }                          // Categorical: counts [id][feature][level]
+    PM2_DEV long long *nbs() const { return (long long *)(b + d->o_nbs); }              // NegBinom: sums [id][feature]
     PM2_DEV int *dl() const { return (int *)(b + d->o_dl); }
     PM2_DEV u8 *sstar() const { return (u8 *)(b + d->o_sstar); }
     PM2_DEV double *lpx() const { return (double *)(b + d->o_cdf); }                      // log-predictives of the uncached clusters beyond XCAP
@@ -247,6 +306,7 @@ struct DV {      // view of one dataset: LDS block + arena
     int base;            // LDS offset of the dataset block
     int trb;             // LDS offset of its transient rows
     int N, P, D, Dp, cols_l, idcap;
+    int kind, Lc;        // cluster type of the dataset (K_GAUSSIAN / K_CATEGORICAL / K_NEGBINOM); Categorical: levels per feature in the pool
     const PM2_CONST Layout *lay;
     Arena ar;
     PM2_DEV int *dsc() const { return lds<int>(base + lay->dsc); }
@@ -290,121 +350,6 @@ struct DV {      // view of one dataset: LDS block + arena
     PM2_DEV void xid_set(int e, int id) const { if (e < XCAP) lds<int>(base + lay->xid)[e] = id; else PM2_G(int, ar.xidx())[e - XCAP] = id; }
 };
 
-PM2_DEV double shfl_d(double v, int src)
-{
-    union { double d; u64 u; } a, b;
-    a.d = v;
-    b.u = PM2_SHFL64(a.u, src);
-    return b.d;
-}
-PM2_DEV int shfl_i(int v, int src) { return (int)(unsigned)PM2_SHFL64((u64)(unsigned)v, src); }
-#ifdef PM2_EMU
-// the value of lane `src` (wave-uniform)
-PM2_DEV int readlane_i(int v, int src) { return shfl_i(v, src); }
-PM2_DEV u64 readlane_u64(u64 v, int src) { return PM2_SHFL64(v, src); }
-PM2_DEV double wave_max_d(double v)
-{
-    const int lane = PM2_TID() & 63;
-    for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = (t > v) ? t : v; }
-    return v;
-}
-PM2_DEV double wave_min_d(double v)
-{
-    const int lane = PM2_TID() & 63;
-    for (int o = 1; o < 64; o <<= 1) { const double t = shfl_d(v, lane ^ o); v = (t < v) ? t : v; }
-    return v;
-}
-PM2_DEV double prev_lane_d(double v) { const int lane = PM2_TID() & 63; return shfl_d(v, lane ? lane - 1 : 0); }
-// (the device's order: quad, quad pair, half row, row, then (r0 + r1) + (r2 + r3) over the four rows of sixteen lanes)
-PM2_DEV double wave_sum_d(double v)
-{
-    const int lane = PM2_TID() & 63;
-    v = v + shfl_d(v, lane ^ 1);
-    v = v + shfl_d(v, lane ^ 2);
-    v = v + shfl_d(v, (lane & ~7) | (7 - (lane & 7)));         // row_half_mirror
-    v = v + shfl_d(v, (lane & ~15) | (15 - (lane & 15)));      // row_mirror
-    return (shfl_d(v, 0) + shfl_d(v, 16)) + (shfl_d(v, 32) + shfl_d(v, 48));
-}
-#else
-// the value of lane `src` (wave-uniform): v_readlane, no LDS round trip
-PM2_DEV int readlane_i(int v, int src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }
-PM2_DEV u64 readlane_u64(u64 v, int src)
-{
-    const int s_ = __builtin_amdgcn_readfirstlane(src);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, s_), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), s_);
-    return ((u64)hi << 32) | (u64)lo;
-}
-// wave-level reductions of a double on the DPP network: xor-1 and xor-2 inside quads, half-row and row mirrors give every lane its
-// 16-lane row total; the four row totals are read with v_readlane.  All 64 lanes must be active.
-template <int CTRL> PM2_DEV double dpp_d(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-PM2_DEV double readlane_d(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-PM2_DEV double wave_sum_d(double v)
-{
-    v += dpp_d<0xB1>(v);      // quad_perm [1,0,3,2]
-    v += dpp_d<0x4E>(v);      // quad_perm [2,3,0,1]
-    v += dpp_d<0x141>(v);     // row_half_mirror
-    v += dpp_d<0x140>(v);     // row_mirror
-    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
-}
-PM2_DEV double wave_max_d(double v)
-{
-    double t;
-    t = dpp_d<0xB1>(v); v = (t > v) ? t : v;
-    t = dpp_d<0x4E>(v); v = (t > v) ? t : v;
-    t = dpp_d<0x141>(v); v = (t > v) ? t : v;
-    t = dpp_d<0x140>(v); v = (t > v) ? t : v;
-    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
-    const double m01 = (r1 > r0) ? r1 : r0, m23 = (r3 > r2) ? r3 : r2;
-    return (m23 > m01) ? m23 : m01;
-}
-// the value of the lane below (lane 0 keeps its own): one DPP shift across the whole wave, no LDS round trip
-PM2_DEV double prev_lane_d(double v) { return dpp_d<0x138>(v); }      // wave_shr:1
-PM2_DEV double wave_min_d(double v)
-{
-    double t;
-    t = dpp_d<0xB1>(v); v = (t < v) ? t : v;
-    t = dpp_d<0x4E>(v); v = (t < v) ? t : v;
-    t = dpp_d<0x141>(v); v = (t < v) ? t : v;
-    t = dpp_d<0x140>(v); v = (t < v) ? t : v;
-    const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
-    const double m01 = (r1 < r0) ? r1 : r0, m23 = (r3 < r2) ? r3 : r2;
-    return (m23 < m01) ? m23 : m01;
-}
-#endif
-// exclusive prefix sum of an int over the wave, and the total
-#ifdef PM2_EMU
-PM2_DEV int wave_excl_scan_i(int v, int &total)
-{
-    const int lane = PM2_TID() & 63;
-    int inc = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = shfl_i(inc, lane - o); if (lane >= o) inc += t; }
-    total = shfl_i(inc, 63);
-    return inc - v;
-}
-#else
-// (the DPP network: shifts inside the rows of sixteen lanes, then the row totals broadcast into the rows above; all lanes active)
-PM2_DEV int wave_excl_scan_i(int v, int &total)
-{
-    int inc = v;
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, false);      // row_shr:1
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, false);      // row_shr:2
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, false);      // row_shr:4
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, false);      // row_shr:8
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
-    total = __builtin_amdgcn_readlane(inc, 63);
-    return inc - v;
-}
-#endif
 // set bits strictly below bit p of a bitmap of 64-bit words
 PM2_DEV int popc_below64(const u64 *bm, int p)
 {
@@ -430,9 +375,14 @@ struct RegArr<Tp, 1> {
     PM2_DEV void set(int i, Tp x) { head = (i == 0) ? x : head; }
 };
 
+// (the levels per feature of a Categorical dataset's pool rows: read here, ahead of the layout shorthand `L` of the struct below)
+template <class Ds> PM2_DEV int ds_levels(const Ds &d) { return d.L; }
+
 // ------------------------------------------------------------------------------------------------------------------------------------
-template <int K, int PPL>
+template <int K, int PPL, int NW>
 struct Sweep2 {
+    static constexpr int T = 64 * NW;       // threads of the workgroup: NW waves, the first K of them own a dataset each
+    static_assert(NW >= K && NW <= NWMAX, "one owner wave per dataset");
     // ---- per-lane state ----
     RegArr<double, PPL> lw;
     static constexpr int NCP = (PPL + 1) / 2;
@@ -494,7 +444,7 @@ struct Sweep2 {
     {
         DV v;
         v.base = L.ds0 + k * L.ds_stride; v.trb = L.tr + k * L.tr_stride;
-        v.N = N; v.P = P; v.D = ap->ds[k].D; v.Dp = L.Dp; v.cols_l = L.cols_l; v.idcap = L.idcap; v.lay = &ap->s2;
+        v.N = N; v.P = P; v.D = ap->ds[k].D; v.kind = ap->ds[k].kind; v.Lc = ds_levels(ap->ds[k]); v.Dp = L.Dp; v.cols_l = L.cols_l; v.idcap = L.idcap; v.lay = &ap->s2;
         v.ar.d = &ap->ds[k];
         v.ar.b = ap->ds[k].arena + (size_t)chain * ap->ds[k].stride;
         return v;
@@ -504,10 +454,116 @@ struct Sweep2 {
     PM2_DEV long long *wk(int k) const { return lds<long long>(L.wk) + k * 8; }
     PM2_DEV const u8 *flk(int k) const { return lds<u8>(L.xfl) + k * 64; }
 
+    // ---- the three cluster types (src/datatypes/{gaussian,categorical,negbinom}_cluster.jl), lane = feature ------------------------------
+    // An observation's value of the lane's feature travels as a double for every type (levels and counts are integers below 2^30:
+    // exact); so do the statistics a step touches: Gaussian (Sigma, beta); Categorical: the count of the observed level;
+    // NegBinom: the feature's sum (below 2^53: exact).
+    struct St { double a, b; };
+    PM2_DEV double obs_x(int k, int i) const
+    {
+        const auto &d = ap->ds[k];
+        if (lane >= d.D) return 0.0;
+        if (d.kind == K_GAUSSIAN) return PM2_G(const double, d.xf)[(size_t)i * d.D + lane];
+        return (double)PM2_G(const int, d.xi)[(size_t)i * d.D + lane];
+    }
+    PM2_DEV St st_load(const DV &v, int id, double x, bool act) const
+    {
+        St st;
+        st.a = 0.0; st.b = 0.5;
+        if (!act) return st;
+        if (v.kind == K_GAUSSIAN) {
+            auto sb = PM2_G(const double, v.ar.sb());
+            st.a = sb[((size_t)id * v.D + lane) * 2]; st.b = sb[((size_t)id * v.D + lane) * 2 + 1];
+        } else if (v.kind == K_CATEGORICAL) {
+            st.a = (double)PM2_G(const int, v.ar.cnt())[((size_t)id * v.D + lane) * v.Lc + ((int)x - 1)];
+        } else {
+            st.a = (double)PM2_G(const long long, v.ar.nbs())[(size_t)id * v.D + lane];
+        }
+        return st;
+    }
+    // cluster_add! of the observation, in place, for the lane's feature (gaussian_cluster.jl:54-66, categorical_cluster.jl:43-51,
+    // negbinom_cluster.jl:43-51): the statistics as st_load returned them, the cluster's new size
+    PM2_DEV void st_add_store(const DV &v, int id, St &st, double x, int nnew, bool on) const
+    {
+        if (!on) return;
+        if (v.kind == K_GAUSSIAN) {
+            pmdi_arith::gauss_add_sb(x, nnew, st.a, st.b);
+            auto sb = PM2_G(double, v.ar.sb());
+            sb[((size_t)id * v.D + lane) * 2] = st.a; sb[((size_t)id * v.D + lane) * 2 + 1] = st.b;
+        } else if (v.kind == K_CATEGORICAL) {
+            st.a = st.a + 1.0;
+            PM2_G(int, v.ar.cnt())[((size_t)id * v.D + lane) * v.Lc + ((int)x - 1)] = (int)st.a;
+        } else {
+            st.a = st.a + x;
+            PM2_G(long long, v.ar.nbs())[(size_t)id * v.D + lane] = (long long)st.a;
+        }
+    }
+    // the per-feature term(s) of calc_logprob for a cluster of size cn whose statistics (as st_load returned them) are st.
+    // Gaussian: both terms of gaussian_cluster.jl:45-48; Categorical: log(nlevels_q + n) and log(0.5 + counts[x_q, q])
+    // (categorical_cluster.jl:30,35-38; the n == 0 branch reads log(0.5)); NegBinom: the six loggammas of negbinom_cluster.jl:33-37 (tb).
+    // Integer types read the host-built tables, so their log-predictives are the bits a CPU evaluation with the same libm gives.
+    PM2_DEV void st_terms(const DV &v, int k, int cn, const St &st, double x, double &ta, double &tb) const
+    {
+        const auto &d = ap->ds[k];
+        if (v.kind == K_GAUSSIAN) {
+            double mu, lam;
+            pmdi_arith::gauss_ml(cn, st.a, st.b, mu, lam);
+            const double nd_ = (double)cn, dd = x - mu;
+            ta = 0.5 * log(lam / (nd_ + 1.0));
+            tb = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
+        } else if (v.kind == K_CATEGORICAL) {
+            auto lh = PM2_G(const double, d.lhtab);
+            ta = lh[PM2_G(const int, d.maxcol)[lane] + 2 * cn];
+            tb = (cn == 0) ? lh[1] : lh[2 * (int)st.a + 1];
+        } else {
+            auto lg = PM2_G(const double, d.lgtab);
+            const long long n_ = cn, x_ = (long long)x, S_ = (long long)st.a;
+            ta = 0.0;
+            tb = lg[1 + n_ + 1] + lg[1 + x_ + S_] + lg[1 + n_ + 1 + S_] - lg[1 + n_ + 1 + 1 + x_ + S_] - lg[1 + n_] - lg[1 + S_];
+        }
+    }
+    // calc_logprob's sum over the features that are switched on, in feature order (one lane): the same terms in the same order as
+    // the reference's loops (gaussian_cluster.jl:41-50; categorical_cluster.jl:30 then :35-38; negbinom_cluster.jl:25-40)
+    PM2_DEV double ordered_sum(int kind, const double *ta, const double *tb, int D, const u8 *fl, bool all_on, double g0) const
+    {
+        double out;
+        if (kind == K_GAUSSIAN) {
+            out = g0;
+            if (all_on) {                       // all features on: fetch eight features' terms, then add them in order
+                for (int q0 = 0; q0 < D; q0 += 8) {
+                    double ra[8], rb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int q = (q0 + u < D) ? q0 + u : D - 1; ra[u] = ta[q]; rb[u] = tb[q]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (q0 + u < D) { out += ra[u]; out -= rb[u]; }
+                }
+            } else {
+                for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
+            }
+        } else if (kind == K_CATEGORICAL) {
+            double acc = 0.0;
+            for (int q = 0; q < D; ++q) if (fl[q]) acc += ta[q];
+            out = -acc;
+            for (int q = 0; q < D; ++q) if (fl[q]) out += tb[q];
+        } else {
+            out = 0.0;
+            for (int q = 0; q < D; ++q) if (fl[q]) out += tb[q];
+        }
+        return out;
+    }
+
     // ---- cluster cache (owner wave) -------------------------------------------------------------------------------------------
-    // load the statistics of cluster `id` into slot s0 (uniform) of the owner wave: lane = feature
+    // cluster `id` of size cnv takes slot s0 (uniform) of the owner wave, lane = feature.  Gaussian: (mu, lambda) from its statistics
+    // into the wave's registers, the first term of every feature and the prefix constant into LDS.  Categorical: the first term
+    // (it depends on the size only).  The integer types read their statistics from the pool at every step.
     PM2_DEV void cache_fill(const DV &v, int k, int s0, double sg, double bt, int cnv, bool defer = false, bool have_g = false, double g_in = 0.0)
     {
+        if (v.kind != K_GAUSSIAN) {
+            if (v.kind == K_CATEGORICAL && lane < v.D)
+                v.ta_row(s0)[lane] = PM2_G(const double, ap->ds[k].lhtab)[PM2_G(const int, ap->ds[k].maxcol)[lane] + 2 * cnv];
+            if (lane == 0) lds<int>(v.base + L.slot_cn)[s0] = cnv;
+            return;
+        }
         double mu, lam;
         pmdi_arith::gauss_ml(cnv, sg, bt, mu, lam);
 #pragma unroll
@@ -584,7 +640,7 @@ struct Sweep2 {
         PM2_WAVE_BARRIER();
         // fresh clusters and the first n1-1 shuffled observations joining their previous cluster, sequentially in shuffled
         // order (:189,:194,:201-206): lane = feature, one label after the other
-        {
+        if (d.kind == K_GAUSSIAN) {
             auto sb = PM2_G(double, v.ar.sb());
             auto xf = PM2_G(const double, d.xf);
             if (lane < D) { sb[((size_t)1 * D + lane) * 2] = 0.0; sb[((size_t)1 * D + lane) * 2 + 1] = 0.5; }
@@ -602,6 +658,42 @@ struct Sweep2 {
                     }
                 }
                 if (lane < D) { sb[((size_t)id * D + lane) * 2] = sg; sb[((size_t)id * D + lane) * 2 + 1] = bt; }
+            }
+        } else if (d.kind == K_CATEGORICAL) {
+            // counts[level, feature] (categorical_cluster.jl:43-51): the lane's feature, one level after the other (the count of a level
+            // is a sum over the label's observations: no order to keep)
+            auto cn_ = PM2_G(int, v.ar.cnt());
+            auto xi = PM2_G(const int, d.xi);
+            const int Lc = v.Lc;
+            if (lane < D) for (int l = 0; l < Lc; ++l) cn_[((size_t)1 * D + lane) * Lc + l] = 0;
+            for (int u = 0; u < N; ++u) {
+                const int id = lab[64 + u];
+                if (!id) continue;
+                if (lane < D) for (int l = 0; l < Lc; ++l) cn_[((size_t)id * D + lane) * Lc + l] = 0;
+                if (lane < D && fl[lane]) {
+                    for (long long j = 0; j < n1 - 1; ++j) {
+                        const int i = order[j];
+                        if (s_in[i] != u) continue;
+                        cn_[((size_t)id * D + lane) * Lc + (xi[(size_t)i * D + lane] - 1)] += 1;
+                    }
+                }
+            }
+        } else {
+            auto nb_ = PM2_G(long long, v.ar.nbs());
+            auto xi = PM2_G(const int, d.xi);
+            if (lane < D) nb_[(size_t)1 * D + lane] = 0;
+            for (int u = 0; u < N; ++u) {
+                const int id = lab[64 + u];
+                if (!id) continue;
+                long long S = 0;
+                if (lane < D && fl[lane]) {
+                    for (long long j = 0; j < n1 - 1; ++j) {
+                        const int i = order[j];
+                        if (s_in[i] != u) continue;
+                        S += xi[(size_t)i * D + lane];                                 // negbinom_cluster.jl:43-51
+                    }
+                }
+                if (lane < D) nb_[(size_t)id * D + lane] = S;
             }
         }
         if (lane == 0) {
@@ -633,10 +725,6 @@ struct Sweep2 {
         // while nothing it depends on has changed (phase C and the resampling say so): most steps of a settled chain
         unsigned needmask = 0;
         int nx = 0;
-#ifdef PM2_EMU
-        if (getenv("PM2_FORCE_DIRTY") && lane == 0) dsc[DS_DIRTY] = 1;
-        PM2_WAVE_BARRIER();
-#endif
         if (PM2_UNI(dsc[DS_DIRTY]) == 0) { needmask = (unsigned)PM2_UNI(dsc[DS_NEEDMASK]); nx = PM2_UNI(dsc[DS_NX]); }
         else {
         // the leaders' columns, four classes at a time: cache slots in use; new_id of the (class, label) keys, fetched now (four loads in
@@ -649,9 +737,6 @@ struct Sweep2 {
                 nid_pref[j] = 0;
                 if (r < ncls) {
                     const int lc = lds<int>(v.base + L.leadcol)[r];
-#ifdef PM2_EMU
-                    if (lc < 0 || lc >= P) { fprintf(stderr, "phase_a: pos %lld k %d r %d ncls %d leadcol %d (lane %d)\n", pos, k, r, ncls, lc, lane); abort(); }
-#endif
                     const int id = (lane < N) ? v.tab_get(lc, lane) : 0;
                     const int s = (lane < N) ? v.slot_of(id) : NONE8;
                     for (int sb_ = 0; sb_ < NS; ++sb_) if (PM2_BALLOT(s == sb_)) needmask |= 1u << sb_;
@@ -685,10 +770,8 @@ struct Sweep2 {
                             v.slot_set(id0, s0);
                         }
                         needmask |= 1u << s0;
-                        auto sb = PM2_G(const double, v.ar.sb());
-                        double sg = 0.0, bt = 0.5;
-                        if (lane < D) { sg = sb[((size_t)id0 * D + lane) * 2]; bt = sb[((size_t)id0 * D + lane) * 2 + 1]; }
-                        cache_fill(v, k, s0, sg, bt, v.cn_get(id0));
+                        const St st0 = st_load(v, id0, x, lane < D && v.kind == K_GAUSSIAN);
+                        cache_fill(v, k, s0, st0.a, st0.b, v.cn_get(id0));
                         row = s0;
                     } else {
                         if (lane == 0) v.xid_set(nx, id0);
@@ -709,78 +792,71 @@ struct Sweep2 {
             if (lane < NS && ((dead >> lane) & 1u)) { const int old = slot_id[lane]; if (old) { v.slot_set(old, NONE8); slot_id[lane] = 0; } }
         }
         const int nneed = __builtin_popcount(needmask) + nx;
-#ifdef PM2_EMU
-        if (lane == 0 && nx > XCAP && getenv("PM2_DEBUG_NX")) fprintf(stderr, "phase_a: pos %lld k %d: %d uncached clusters (XCAP %d)\n", pos, k, nx, XCAP);
-#endif
         if (lane == 0) { dsc[DS_NX] = nx; dsc[DS_NNEED] = nneed; dsc[DS_NEEDMASK] = (int)needmask; }
         PM2_WAVE_BARRIER();
         }
         PHD(1);
-        // -- A2: the per-feature terms: cached clusters need one log per feature (gaussian_cluster.jl:46-48), lane = feature
+        // -- A2: the per-feature terms, lane = feature.  Gaussian: cached clusters need one log per feature (gaussian_cluster.jl:46-48).
+        // Integer types: the statistics of all needed slots from the pool (the loads in flight together), then the table look-ups
+        if (v.kind == K_GAUSSIAN) {
 #pragma nounroll
-        for (int s = 0; s < NS; ++s) {
-            if ((needmask >> s) & 1u) {
-                const double mu = c_mu[s], lam = c_lam[s];
-                const double nd_ = (double)lds<int>(v.base + L.slot_cn)[s];
-                const double dd = x - mu;
-                const double tb = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
-                if (lane < D) v.tb_row(s)[lane] = tb;
+            for (int s = 0; s < NS; ++s) {
+                if ((needmask >> s) & 1u) {
+                    const double mu = c_mu[s], lam = c_lam[s];
+                    const double nd_ = (double)lds<int>(v.base + L.slot_cn)[s];
+                    const double dd = x - mu;
+                    const double tb = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
+                    if (lane < D) v.tb_row(s)[lane] = tb;
+                }
+            }
+        } else {
+            St sv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) sv[s] = st_load(v, slot_id[s], x, on && ((needmask >> s) & 1u));
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (on && ((needmask >> s) & 1u)) {
+                    double ta_, tb_;
+                    st_terms(v, k, lds<int>(v.base + L.slot_cn)[s], sv[s], x, ta_, tb_);       // (Categorical: the first term was stored when the slot was filled)
+                    v.tb_row(s)[lane] = tb_;
+                }
             }
         }
         PHD(2);
-        // -- A3: ordered sums, one lane per cluster row (calc_logprob's loop, gaussian_cluster.jl:41-50, same terms, same order)
+        // -- A3: ordered sums, one lane per cluster row (calc_logprob's loop, same terms, same order)
         double *lp = v.lp();
         PM2_WAVE_BARRIER();
-        if (lane < NS && ((needmask >> lane) & 1u)) {
-            const double *ta = v.ta_row(lane), *tb = v.tb_row(lane);
-            double out = lds<double>(v.base + L.slot_g)[lane];
-            if (dsc[DS_NFLAG] == D) {           // all features on: fetch eight features' terms, then add them in order
-                for (int q0 = 0; q0 < D; q0 += 8) {
-                    double ra[8], rb[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { const int q = (q0 + u < D) ? q0 + u : D - 1; ra[u] = ta[q]; rb[u] = tb[q]; }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) if (q0 + u < D) { out += ra[u]; out -= rb[u]; }
-                }
-            } else {
-                for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
-            }
-            lp[lane] = out;
-        }
+        if (lane < NS && ((needmask >> lane) & 1u))
+            lp[lane] = ordered_sum(v.kind, v.ta_row(lane), v.tb_row(lane), D, fl, dsc[DS_NFLAG] == D, lds<double>(v.base + L.slot_g)[lane]);
         PHD(3);
         // uncached reachable clusters, XR per round: statistics from the pool, both terms on the fly into the tb rows (the cached
         // clusters' sums are done with them): rows 2j, 2j + 1 for the j-th cluster of the round; then one lane per cluster adds
         for (int e0 = 0; e0 < nx; e0 += XR) {
             PM2_WAVE_BARRIER();
             {
-                auto sb = PM2_G(const double, v.ar.sb());
                 int idj[XR], cnj[XR];
-                double sgj[XR], btj[XR];
+                St stj[XR];
 #pragma unroll
                 for (int j = 0; j < XR; ++j) {
                     idj[j] = (e0 + j < nx) ? v.xid_get(e0 + j) : 0;
                     cnj[j] = idj[j] ? v.cn_get(idj[j]) : 0;
-                    sgj[j] = 0.0; btj[j] = 0.5;
-                    if (on && idj[j]) { sgj[j] = sb[((size_t)idj[j] * D + lane) * 2]; btj[j] = sb[((size_t)idj[j] * D + lane) * 2 + 1]; }
+                    stj[j] = st_load(v, idj[j], x, on && idj[j] != 0);
                 }
 #pragma unroll
                 for (int j = 0; j < XR; ++j) {
                     if (on && idj[j]) {
-                        double mu, lam;
-                        pmdi_arith::gauss_ml(cnj[j], sgj[j], btj[j], mu, lam);
-                        const double nd_ = (double)cnj[j], dd = x - mu;
-                        v.tb_row(2 * j)[lane] = 0.5 * log(lam / (nd_ + 1.0));
-                        v.tb_row(2 * j + 1)[lane] = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
+                        double ta_, tb_;
+                        st_terms(v, k, cnj[j], stj[j], x, ta_, tb_);
+                        v.tb_row(2 * j)[lane] = ta_;
+                        v.tb_row(2 * j + 1)[lane] = tb_;
                     }
                 }
             }
             PM2_WAVE_BARRIER();
             if (lane < XR && e0 + lane < nx) {
                 const int id = v.xid_get(e0 + lane);
-                const double *ta = v.tb_row(2 * lane), *tb = v.tb_row(2 * lane + 1);
-                double out = (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[v.cn_get(id)];
-                for (int q = 0; q < D; ++q) if (fl[q]) { out += ta[q]; out -= tb[q]; }
-                v.lp_set(NS + e0 + lane, out);
+                const double g0 = (v.kind == K_GAUSSIAN) ? (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[v.cn_get(id)] : 0.0;
+                v.lp_set(NS + e0 + lane, ordered_sum(v.kind, v.tb_row(2 * lane), v.tb_row(2 * lane + 1), D, fl, false, g0));
             }
         }
         PM2_WAVE_BARRIER();
@@ -852,19 +928,6 @@ struct Sweep2 {
                 PM2_WAVE_BARRIER();
             }
         }
-#ifdef PM2_EMU
-        if (getenv("PM2_DEBUG") && lane == 0 && pos - (n1 - 1) <= atoi(getenv("PM2_DEBUG"))) {
-            for (int r = 0; r < ncls; ++r) {
-                fprintf(stderr, "E pos %lld k %d class %d leader %d inc %.17g ids:", pos, k, lds<int>(v.base + L.clsval)[r], lds<int>(v.base + L.clslead)[r], v.cdf_row(r)[N]);
-                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %d", v.tab_get(lds<int>(v.base + L.leadcol)[r], nn));
-                fprintf(stderr, " lp:");
-                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", v.lp_get(itemj[r * N + nn]));
-                fprintf(stderr, " cdf:");
-                for (int nn = 0; nn < N; ++nn) fprintf(stderr, " %.17g", v.cdf_row(r)[nn]);
-                fprintf(stderr, "\n");
-            }
-        }
-#endif
         if (lane == 0) dsc[DS_NS0] = ns0_cur;             // reference trajectory (:262), fetched a step ago
         PHD(15);
         (void)pos;
@@ -912,12 +975,7 @@ struct Sweep2 {
         unsigned *minp = lds<unsigned>(v.base + L.minp);
         u64 *bmc = lds<u64>(v.base + L.bmc), *bmf = lds<u64>(v.base + L.bmf);
         // the statistics of the first chosen cluster (the only one in most steps), on their way while the bookkeeping runs
-        double pf_sg = 0.0, pf_bt = 0.5;
-        if (nd > 0 && lane < D) {
-            auto sb0 = PM2_G(const double, v.ar.sb());
-            const int c0 = chosen(0);
-            pf_sg = sb0[((size_t)c0 * D + lane) * 2]; pf_bt = sb0[((size_t)c0 * D + lane) * 2 + 1];
-        }
+        const St pf = st_load(v, nd > 0 ? chosen(0) : 0, x, nd > 0 && lane < D);
         PHD(12);
         PHC(1);
         // -- C0: the step of a settled chain, most of the time: one class, every particle drew the same label and the same cluster,
@@ -929,14 +987,9 @@ struct Sweep2 {
             if (v.ncop_get(c) == v.counts_get(c) && v0 > 0 && v0 == lds<int>(v.base + L.clsval)[0]) {
                 const int nnew = v.cn_get(c) + 1;
                 const int s0 = v.slot_of(c);
-                double sg = pf_sg, bt = pf_bt;
-                const bool on = lane < D && fl[lane];
-                if (on) {
-                    pmdi_arith::gauss_add_sb(x, nnew, sg, bt);
-                    auto sb = PM2_G(double, v.ar.sb());
-                    sb[((size_t)c * D + lane) * 2] = sg; sb[((size_t)c * D + lane) * 2 + 1] = bt;
-                }
-                if (s0 != NONE8) cache_fill(v, k, s0, sg, bt, nnew, true);
+                St st = pf;
+                st_add_store(v, c, st, x, nnew, lane < D && fl[lane]);
+                if (s0 != NONE8) cache_fill(v, k, s0, st.a, st.b, nnew, true);
                 for (int cc = lane; cc < ncol; cc += 64) v.cmask_set(cc, 0);
                 PM2_WAVE_BARRIER();
                 if (lane == 0) {
@@ -967,6 +1020,7 @@ struct Sweep2 {
         int nclone = 0;
         for (int w = 0; w < P / 64; ++w) nclone += pm2_popc64(bmc[w]);
         if (maxid + nclone > ap->cap) { if (lane == 0) sc()[SC_FAIL] = 1; return false; }      // PMDI_E_POOL
+        if (maxid + nclone > 0xFFFF) { if (lane == 0) sc()[SC_FAIL] = 3; return false; }       // (ids travel as 16-bit values in the LDS tables: the general kernel's chain)
         for (int e0 = 0; e0 < nd; e0 += 64) {
             const int e = e0 + lane;
             if (e < nd) {
@@ -1172,14 +1226,6 @@ struct Sweep2 {
             }
         }
         PM2_WAVE_BARRIER();
-#ifdef PM2_EMU
-        if (getenv("PM2_DEBUG") && lane == 0) {
-            fprintf(stderr, "C pos %lld k %d: nd %d nk %d nrep %d nclone %d ncol %d->%d maxid %d |", pos, k, nd, nk, nrep, nclone, ncol, ncol_new, maxid);
-            for (int j = 0; j < nk; ++j) fprintf(stderr, " key %d val %d rep %d p %u col %u;", klist[j], kval[j], krep[j], minp[klist[j]] >> 16, minp[klist[j]] & 0xffff);
-            for (int r = 0; r < nrep; ++r) fprintf(stderr, " cls[%d]=(%d,%d,%d)", r, lds<int>(v.base + L.clsval)[r], lds<int>(v.base + L.clslead)[r], lds<int>(v.base + L.leadcol)[r]);
-            fprintf(stderr, "\n");
-        }
-#endif
         PHD(13);
         PHC(7);
         int ndefer = 0;
@@ -1191,12 +1237,12 @@ struct Sweep2 {
             // the first term anyway); every other chosen cluster -- uncached, or cloned -- is left to the statistics phase behind the
             // next workgroup barrier, where all four waves share them (help_stats).  Four clusters at a time: table entries, then the
             // statistics and prefix constants (all loads in flight together), then the arithmetic.
-            auto sb = PM2_G(double, v.ar.sb());
             const bool on = lane < D && fl[lane];
             for (int e0 = 0; e0 < nd; e0 += 4) {
                 int cj[4], nj[4], sj[4];
                 bool mine[4];
-                double sgj[4], btj[4], gj[4];
+                St stj[4];
+                double gj[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     cj[j] = 0; nj[j] = 0; sj[j] = NONE8; mine[j] = false;
@@ -1209,21 +1255,17 @@ struct Sweep2 {
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    sgj[j] = pf_sg; btj[j] = pf_bt; gj[j] = 0.0;
+                    stj[j] = pf; gj[j] = 0.0;
                     if (mine[j]) {
-                        if (e0 + j > 0 && lane < D) { sgj[j] = sb[((size_t)cj[j] * D + lane) * 2]; btj[j] = sb[((size_t)cj[j] * D + lane) * 2 + 1]; }
-                        if (lane == 0) gj[j] = PM2_G(const double, d.gtab)[nj[j]];
+                        if (e0 + j > 0) stj[j] = st_load(v, cj[j], x, lane < D);
+                        if (lane == 0 && v.kind == K_GAUSSIAN) gj[j] = PM2_G(const double, d.gtab)[nj[j]];
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (mine[j]) {
-                        double sg = sgj[j], bt = btj[j];
-                        if (on) {
-                            pmdi_arith::gauss_add_sb(x, nj[j], sg, bt);
-                            sb[((size_t)cj[j] * D + lane) * 2] = sg; sb[((size_t)cj[j] * D + lane) * 2 + 1] = bt;
-                        }
-                        cache_fill(v, k, sj[j], sg, bt, nj[j], false, true, gj[j]);
+                        st_add_store(v, cj[j], stj[j], x, nj[j], on);
+                        cache_fill(v, k, sj[j], stj[j].a, stj[j].b, nj[j], false, true, gj[j]);
                     }
                 }
             }
@@ -1289,8 +1331,8 @@ struct Sweep2 {
             double x = 0.0;
             bool have_x = false;
             for (int e0 = 0; e0 < nd; e0 += HB, ++item) {
-                if ((item & 3) != wave) continue;
-                if (!have_x) { if (lane < D) x = PM2_G(const double, d.xf)[(size_t)i_cur * D + lane]; have_x = true; }
+                if (item % NW != wave) continue;
+                if (!have_x) { x = obs_x(k, i_cur); have_x = true; }
                 int cj[HB], tj[HB], nj[HB];
                 bool mine[HB];
                 double sgj[HB], btj[HB];
@@ -1305,18 +1347,40 @@ struct Sweep2 {
                         if (mine[j]) nj[j] = v.cn_get(tj[j]);
                     }
                 }
+                if (v.kind == K_GAUSSIAN) {
 #pragma unroll
-                for (int j = 0; j < HB; ++j) {
-                    sgj[j] = 0.0; btj[j] = 0.5;
-                    if (mine[j] && lane < D) { sgj[j] = sb[((size_t)cj[j] * D + lane) * 2]; btj[j] = sb[((size_t)cj[j] * D + lane) * 2 + 1]; }
-                }
-#pragma unroll
-                for (int j = 0; j < HB; ++j) {
-                    if (mine[j]) {
-                        double sg = sgj[j], bt = btj[j];
-                        if (on) pmdi_arith::gauss_add_sb(x, nj[j], sg, bt);
-                        if (lane < D && (on || tj[j] != cj[j])) { sb[((size_t)tj[j] * D + lane) * 2] = sg; sb[((size_t)tj[j] * D + lane) * 2 + 1] = bt; }
+                    for (int j = 0; j < HB; ++j) {
+                        sgj[j] = 0.0; btj[j] = 0.5;
+                        if (mine[j] && lane < D) { sgj[j] = sb[((size_t)cj[j] * D + lane) * 2]; btj[j] = sb[((size_t)cj[j] * D + lane) * 2 + 1]; }
                     }
+#pragma unroll
+                    for (int j = 0; j < HB; ++j) {
+                        if (mine[j]) {
+                            double sg = sgj[j], bt = btj[j];
+                            if (on) pmdi_arith::gauss_add_sb(x, nj[j], sg, bt);
+                            if (lane < D && (on || tj[j] != cj[j])) { sb[((size_t)tj[j] * D + lane) * 2] = sg; sb[((size_t)tj[j] * D + lane) * 2 + 1] = bt; }
+                        }
+                    }
+                } else if (v.kind == K_CATEGORICAL) {
+                    // deepcopy: every level's count of the lane's feature; cluster_add!: the observed level's (categorical_cluster.jl:43-51)
+                    auto cn_ = PM2_G(int, v.ar.cnt());
+                    const int Lc = v.Lc;
+#pragma unroll
+                    for (int j = 0; j < HB; ++j) {
+                        if (mine[j] && lane < D) {
+                            const size_t so = ((size_t)cj[j] * D + lane) * Lc, to = ((size_t)tj[j] * D + lane) * Lc;
+                            const int xl = (int)x - 1;
+                            const int cx = cn_[so + xl];
+                            if (tj[j] != cj[j]) for (int l = 0; l < Lc; ++l) cn_[to + l] = cn_[so + l];
+                            if (on) cn_[to + xl] = cx + 1;
+                        }
+                    }
+                } else {
+                    auto nb_ = PM2_G(long long, v.ar.nbs());
+#pragma unroll
+                    for (int j = 0; j < HB; ++j)
+                        if (mine[j] && lane < D && (on || tj[j] != cj[j]))
+                            nb_[(size_t)tj[j] * D + lane] = nb_[(size_t)cj[j] * D + lane] + (on ? (long long)x : 0ll);       // negbinom_cluster.jl:43-51
                 }
             }
         }
@@ -1330,7 +1394,7 @@ struct Sweep2 {
     PM2_DEV void census(const DV &v, bool active, int mult, int r, int cl, int ns, int c, int p)
     {
         int *dsc = v.dsc();
-        const int key3 = ((r * P + cl) * N + ns) * 8 + mult;
+        const int key3 = ((r * P + cl) * N + ns) * 16 + mult;
         const u64 act = PM2_BALLOT(active);
         if (act == 0) return;
         // the whole wave drew the same (the rule in a settled chain): one lane speaks for it; otherwise every lane for itself -- the
@@ -1506,13 +1570,6 @@ struct Sweep2 {
         if (js >= P) js = P - 1;
         PM2_BARRIER();
         PHR(5);
-#ifdef PM2_EMU
-        if (getenv("PM2_DEBUG") && tid == 0) {
-            fprintf(stderr, "E resample last %.17g u0 %.17g j %d raw:", red[0], utab[0], js);
-            for (int m = 0; m < P; ++m) fprintf(stderr, " %d", (int)raw[m]);
-            fprintf(stderr, "\n");
-        }
-#endif
 #pragma unroll
         for (int uu = 0; uu < PPL; ++uu) {
             const int p = tid * PPL + uu;
@@ -1539,6 +1596,7 @@ struct Sweep2 {
             for (int e = tid; e < ncol_old; e += T) mult[e] = 0;
             for (int e = tid; e <= oldmax && e < v.idcap; e += T) hist[e] = 0;
             if (tid < CLS) lds<int>(L.red)[RI_CLSMIN + tid] = 0x7fffffff;
+            if (tid == 0) sc()[SC_TMP0] = 0;                 // ids moved by this dataset's renumbering (counted below, barriers away)
             PM2_BARRIER();
             // particle[:, partstar, k], particle_id[partstar, k] (:322-323): a particle takes its ancestor's column index and class
 #pragma unroll
@@ -1566,7 +1624,8 @@ struct Sweep2 {
                 if (act) {
                     const int l0 = pm2_ffs64(act) - 1;
                     const int key = cl * CLS + r;
-                    const bool uni = PM2_BALLOT(start && key == readlane_i(key, l0)) == act;
+                    const int key0 = readlane_i(key, l0);             // (every lane reads it: a cross-lane read must not sit behind `start &&`)
+                    const bool uni = PM2_BALLOT(start && key == key0) == act;
                     int tot = cnt;
                     if (uni) {
                         tot = 0;
@@ -1588,10 +1647,10 @@ struct Sweep2 {
                 const int cc = b + tid;
                 const bool live = cc < ncol_old && mult[cc] != 0;
                 const u64 bal = PM2_BALLOT(live);
-                if (lane == 0) lds<int>(L.red)[48 + wave] = pm2_popc64(bal);
+                if (lane == 0) lds<int>(L.red)[RI_WCNT + wave] = pm2_popc64(bal);
                 PM2_BARRIER();
                 int basew = ncol_new, tot = 0;
-                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[48 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
+                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[RI_WCNT + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
                 if (live) cmap[cc] = (u16)(basew + pm2_popc64(bal & ((1ull << lane) - 1ull)));
                 ncol_new += tot;
                 PM2_BARRIER();
@@ -1616,17 +1675,16 @@ struct Sweep2 {
                 if (id <= oldmax) occ = (id < v.idcap) ? hist[id] : PM2_G(int, v.ar.ncop())[id];
                 const bool live = occ != 0;
                 const u64 bal = PM2_BALLOT(live);
-                if (lane == 0) lds<int>(L.red)[48 + wave] = pm2_popc64(bal);
+                if (lane == 0) lds<int>(L.red)[RI_WCNT + wave] = pm2_popc64(bal);
                 PM2_BARRIER();
                 int basew = newmax, tot = 0;
-                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[48 + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
+                for (int w_ = 0; w_ < T / 64; ++w_) { const int cnt = lds<int>(L.red)[RI_WCNT + w_]; if (w_ < wave) basew += cnt; tot += cnt; }
                 if (id <= oldmax) v.tgt_set(id, live ? basew + pm2_popc64(bal & ((1ull << lane) - 1ull)) + 1 : 0);
                 newmax += tot;
                 PM2_BARRIER();
             }
             // counts and cluster sizes move down with their ids, ascending (:336,:338): read a batch, barrier, write it
             PHR(11);
-            if (tid == 0) sc()[SC_TMP0] = 0;
             for (int b = 0; b < oldmax; b += T) {
                 const int id = 1 + b + tid;
                 int nid = 0, occ = 0, cnv = 0;
@@ -1649,19 +1707,49 @@ struct Sweep2 {
             }
             // ... and the statistics: clusters[k][i] = deepcopy(clusters[k][id]) for id > i, ascending batches (:336)
             PHR(12);
-            {
+            if (sc()[SC_TMP0] != 0) {                         // (uniform: written before the barriers of the loop above)
+                // one pool row = W words per id: Gaussian D pairs of doubles, Categorical D x L counts, NegBinom D 64-bit sums
                 const int D = ap->ds[k].D;
-                auto sb = PM2_G(double, v.ar.sb());
-                const long long nitems = (long long)oldmax * D;
-                for (long long b = 0; b < nitems; b += T) {
-                    const long long it = b + tid;
-                    const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
-                    const int nid = (it < nitems) ? v.tgt_get(id) : 0;
-                    const bool mv = nid != 0 && nid != id;
-                    double sg = 0.0, bt = 0.0;
-                    if (mv) { sg = sb[((size_t)id * D + q) * 2]; bt = sb[((size_t)id * D + q) * 2 + 1]; }
-                    PM2_BARRIER();
-                    if (mv) { sb[((size_t)nid * D + q) * 2] = sg; sb[((size_t)nid * D + q) * 2 + 1] = bt; }
+                if (v.kind == K_GAUSSIAN) {
+                    auto sb = PM2_G(double, v.ar.sb());
+                    const long long nitems = (long long)oldmax * D;
+                    for (long long b = 0; b < nitems; b += T) {
+                        const long long it = b + tid;
+                        const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
+                        const int nid = (it < nitems) ? v.tgt_get(id) : 0;
+                        const bool mv = nid != 0 && nid != id;
+                        double sg = 0.0, bt = 0.0;
+                        if (mv) { sg = sb[((size_t)id * D + q) * 2]; bt = sb[((size_t)id * D + q) * 2 + 1]; }
+                        PM2_BARRIER();
+                        if (mv) { sb[((size_t)nid * D + q) * 2] = sg; sb[((size_t)nid * D + q) * 2 + 1] = bt; }
+                    }
+                } else if (v.kind == K_CATEGORICAL) {
+                    auto cn_ = PM2_G(int, v.ar.cnt());
+                    const int W = D * v.Lc;
+                    const long long nitems = (long long)oldmax * W;
+                    for (long long b = 0; b < nitems; b += T) {
+                        const long long it = b + tid;
+                        const int id = 1 + (int)(it / W), q = (int)(it - (long long)(id - 1) * W);
+                        const int nid = (it < nitems) ? v.tgt_get(id) : 0;
+                        const bool mv = nid != 0 && nid != id;
+                        int c_ = 0;
+                        if (mv) c_ = cn_[(size_t)id * W + q];
+                        PM2_BARRIER();
+                        if (mv) cn_[(size_t)nid * W + q] = c_;
+                    }
+                } else {
+                    auto nb_ = PM2_G(long long, v.ar.nbs());
+                    const long long nitems = (long long)oldmax * D;
+                    for (long long b = 0; b < nitems; b += T) {
+                        const long long it = b + tid;
+                        const int id = 1 + (int)(it / D), q = (int)(it - (long long)(id - 1) * D);
+                        const int nid = (it < nitems) ? v.tgt_get(id) : 0;
+                        const bool mv = nid != 0 && nid != id;
+                        long long S_ = 0;
+                        if (mv) S_ = nb_[(size_t)id * D + q];
+                        PM2_BARRIER();
+                        if (mv) nb_[(size_t)nid * D + q] = S_;
+                    }
                 }
             }
             PM2_BARRIER();
@@ -1786,7 +1874,7 @@ struct Sweep2 {
         int i_next = order[n1 - 1];
         int i_next2 = (n1 < n) ? order[n1] : 0;
         if (owner) {
-            if (lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+            xnext = obs_x(wave, i_next);
             ns0_next = PM2_G(const int, a.s_in)[((size_t)chain * K + wave) * n + i_next];
         }
         pend_slot = -1; pend_g = 0.0;
@@ -1800,7 +1888,7 @@ struct Sweep2 {
             if (pos + 1 < n) {
                 i_next = i_next2;
                 if (owner) {
-                    if (lane < a.ds[wave].D) xnext = PM2_G(const double, a.ds[wave].xf)[(size_t)i_next * a.ds[wave].D + lane];
+                    xnext = obs_x(wave, i_next);
                     ns0_next = PM2_G(const int, a.s_in)[((size_t)chain * K + wave) * n + i_next];
                 }
                 if (pos + 2 < n) i_next2 = order[pos + 2];
@@ -1926,15 +2014,15 @@ struct Sweep2 {
 #pragma unroll
                 for (int u = 1; u < PPL; ++u) { mx = (lw[u] > mx) ? lw[u] : mx; mn = (lw[u] < mn) ? lw[u] : mn; }
                 mx = wave_max_d(mx); mn = wave_min_d(mn);
-                if (lane == 0) { red[wave] = mx; red[4 + wave] = mn; }
+                if (lane == 0) { red[RD_MAX + wave] = mx; red[RD_MIN + wave] = mn; }
             }
             PH2(4);
             PM2_BARRIER();
             PH2(5);
             // ---- calc_ESS (src/misc.jl:15-25), first half; the bookkeeping phase of the owner waves.  If every log-weight is the
             // same number the sums are exact (P ones): ESS == P, no exps
-            double mx = red[0], mn = red[4];
-            for (int w_ = 1; w_ < T / 64; ++w_) { mx = (red[w_] > mx) ? red[w_] : mx; mn = (red[4 + w_] < mn) ? red[4 + w_] : mn; }
+            double mx = red[RD_MAX], mn = red[RD_MIN];
+            for (int w_ = 1; w_ < NW; ++w_) { mx = (red[RD_MAX + w_] > mx) ? red[RD_MAX + w_] : mx; mn = (red[RD_MIN + w_] < mn) ? red[RD_MIN + w_] : mn; }
             PHD(10);
             const bool lw_flat = mx == mn;
             if (!lw_flat) {
@@ -1942,7 +2030,7 @@ struct Sweep2 {
 #pragma nounroll
                 for (int u = 0; u < PPL; ++u) { const double w = exp(lw_get(u) - mx); sa += w; sq += w * w; }
                 sa = wave_sum_d(sa); sq = wave_sum_d(sq);
-                if (lane == 0) { red[8 + wave] = sa; red[12 + wave] = sq; }
+                if (lane == 0) { red[RD_SA + wave] = sa; red[RD_SQ + wave] = sq; }
             }
             if (owner) phase_c(wave, x, pos);
             PHC(9);
@@ -1978,7 +2066,7 @@ struct Sweep2 {
             double ess = (double)P;
             if (!lw_flat) {
                 double sa = 0.0, sq = 0.0;
-                for (int w_ = 0; w_ < T / 64; ++w_) { sa += red[8 + w_]; sq += red[12 + w_]; }
+                for (int w_ = 0; w_ < NW; ++w_) { sa += red[RD_SA + w_]; sq += red[RD_SQ + w_]; }
                 ess = (sa * sa) / sq;
             }
             // The tree-ordered sums agree with calc_ESS's sequential loop to ~1e-13 relative; the decision is a comparison, so when

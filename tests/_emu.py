@@ -18,7 +18,7 @@ VARIANTS = {"": [], "xcap2": ["-DPM2_XCAP=2"]}      # (xcap2: two LDS entries fo
 
 def build(force=False, variant=""):
     _LIB = os.path.join(_EMU, f"libpmdi_emu{'_' + variant if variant else ''}.so")
-    deps = [os.path.join(_EMU, "emu_sweep2.cpp"), os.path.join(_EMU, "wavesim.h")] + \
+    deps = [os.path.join(_EMU, "emu_sweep2.cpp"), os.path.join(_EMU, "wavesim.h"), os.path.join(_EMU, "lane_api_emu.h")] + \
            [os.path.join(_CSRC, f) for f in ("pmdi_sweep2_body.h", "pmdi_arith.h", "pmdi_internal.h")]
     if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(d) for d in deps):
         return _LIB
@@ -35,7 +35,7 @@ def lib(variant=""):
         L = C.CDLL(build(variant=variant))
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.emu_create.restype = vp
-        L.emu_create.argtypes = [i32, i64, i32, i32, vp, vp, C.c_uint64, i32, i32, i32]
+        L.emu_create.argtypes = [i32, i64, i32, i32, vp, vp, C.c_uint64, i32, i32, i32, vp]
         L.emu_destroy.argtypes = [vp]
         L.emu_lds_bytes.restype = i64
         L.emu_lds_bytes.argtypes = [vp]
@@ -52,14 +52,16 @@ def _ptr(a):
 class EmuSweeper:
     """One chain of the settled-chain kernel on the emulator; same call shape as the oracle's Oracle.sweep."""
 
-    def __init__(self, data, N, P, seed=0, q1_mode=0, cols_l=64, idcap=128, variant=""):
+    def __init__(self, data, N, P, seed=0, q1_mode=0, cols_l=64, idcap=128, variant="", kinds=None):
         self._L = lib(variant)
         self.K, self.n, self.N, self.P = len(data), int(data[0].shape[0]), int(N), int(P)
         self.D = np.array([x.shape[1] for x in data], dtype=np.int32)
         self._x = [np.ascontiguousarray(x, dtype=np.float64) for x in data]
         ptrs = (C.c_void_p * self.K)(*[x.ctypes.data for x in self._x])
+        code = {"gaussian": 0, "categorical": 1, "negbinom": 2}
+        self._kinds = np.array([code[k] for k in (kinds or ["gaussian"] * self.K)], dtype=np.int32)
         self.h = self._L.emu_create(self.K, self.n, self.N, self.P, _ptr(self.D), C.cast(ptrs, C.c_void_p), int(seed), int(q1_mode),
-                                  int(cols_l), int(idcap))
+                                  int(cols_l), int(idcap), _ptr(self._kinds))
         if not self.h:
             raise ValueError("emu_create rejected the configuration")
         self.lds_bytes = self._L.emu_lds_bytes(self.h)

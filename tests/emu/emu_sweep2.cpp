@@ -7,7 +7,7 @@
 #include <cstring>
 #include <vector>
 
-#define PM2_EMU 1
+#include "lane_api_emu.h"
 #include "../../particlemdi.jl_amd/csrc/pmdi_sweep2_body.h"
 
 namespace {
@@ -38,7 +38,9 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
     d.o_cdf = take((size_t)P * (N + 2) * 8);
     d.o_dl = take((size_t)3 * P * 4);
     d.o_cn = take(ids * 4);
-    d.o_sb = take(ids * d.D * 16);
+    if (d.kind == K_GAUSSIAN) d.o_sb = take(ids * d.D * 16);
+    else if (d.kind == K_CATEGORICAL) d.o_cnt = take(ids * d.D * d.L * 4);
+    else d.o_nbs = take(ids * d.D * 8);
     return o;
 }
 
@@ -47,28 +49,32 @@ struct Emu {
     long long n, cap;
     unsigned long long seed;
     int q1;
-    std::vector<std::vector<double>> x, gtab;
+    std::vector<std::vector<double>> x, gtab, lhtab, lgtab;
+    std::vector<std::vector<int>> xi, maxcol;
     std::vector<std::vector<char>> arena;
     DsetDev ds[PMDI_KMAX_I];
     int Dmax = 0, sumD = 0;
     int cols_l, idcap;
 };
 
-struct RunArg { const SweepArgs *a; int K, PPL; };
+struct RunArg { const SweepArgs *a; int K, PPL, NW; };
 
-template <int K, int PPL> void body(const SweepArgs *a)
+template <int K, int PPL, int NW> void body(const SweepArgs *a)
 {
-    pmdi_s2::Sweep2<K, PPL> s;
+    pmdi_s2::Sweep2<K, PPL, NW> s;
     s.run(a, 0);
 }
 
+// the instantiations of pmdi_sweep2.hip (four waves: 1, 2, 4 particles per lane; eight waves: 4 per lane)
 void entry(void *p)
 {
     const RunArg *r = (const RunArg *)p;
-#define CASE(K_, P_) if (r->K == K_ && r->PPL == P_) return body<K_, P_>(r->a)
-    CASE(1, 1); CASE(1, 2); CASE(1, 4); CASE(2, 1); CASE(2, 2); CASE(2, 4); CASE(3, 1); CASE(3, 2); CASE(3, 4); CASE(4, 1); CASE(4, 2); CASE(4, 4);
+#define CASE(K_, P_, W_) if (r->K == K_ && r->PPL == P_ && r->NW == W_) return body<K_, P_, W_>(r->a)
+    CASE(1, 1, 4); CASE(1, 2, 4); CASE(1, 4, 4); CASE(2, 1, 4); CASE(2, 2, 4); CASE(2, 4, 4); CASE(3, 1, 4); CASE(3, 2, 4); CASE(3, 4, 4);
+    CASE(4, 1, 4); CASE(4, 2, 4); CASE(4, 4, 4);
+    CASE(1, 4, 8); CASE(2, 4, 8); CASE(3, 4, 8); CASE(4, 4, 8);
 #undef CASE
-    fprintf(stderr, "emu: unsupported K=%d PPL=%d\n", r->K, r->PPL);
+    fprintf(stderr, "emu: unsupported K=%d PPL=%d NW=%d\n", r->K, r->PPL, r->NW);
     abort();
 }
 
@@ -76,31 +82,63 @@ void entry(void *p)
 
 extern "C" {
 
-// data[k]: n x D_k row-major doubles
+// data[k]: n x D_k row-major doubles (integer types: levels 1..L / counts >= 0 as doubles); kinds[k]: K_GAUSSIAN / K_CATEGORICAL / K_NEGBINOM
 void *emu_create(int K, long long n, int N, int P, const int *D, const double *const *data, unsigned long long seed, int q1,
-                 int cols_l, int idcap)
+                 int cols_l, int idcap, const int *kinds)
 {
-    if (K < 1 || K > pmdi_s2::KMAX2 || P % 256 != 0 || (P / 256 != 1 && P / 256 != 2 && P / 256 != 4) || N > 64) return nullptr;
+    if (K < 1 || K > pmdi_s2::KMAX2 || (P != 256 && P != 512 && P != 1024 && P != 2048) || N > 64) return nullptr;
     Emu *e = new Emu();
     e->K = K; e->N = N; e->P = P; e->n = n; e->cap = (long long)N * P + 1; e->seed = seed; e->q1 = q1;
     e->cols_l = cols_l; e->idcap = idcap;
     memset(e->ds, 0, sizeof(e->ds));
-    e->x.resize(K); e->gtab.resize(K); e->arena.resize(K);
+    e->x.resize(K); e->gtab.resize(K); e->arena.resize(K); e->lhtab.resize(K); e->lgtab.resize(K); e->xi.resize(K); e->maxcol.resize(K);
     int flag_off = 0;
     for (int k = 0; k < K; ++k) {
         if (D[k] > 64) { delete e; return nullptr; }
         DsetDev &d = e->ds[k];
-        d.kind = K_GAUSSIAN; d.D = D[k]; d.L = 0; d.flag_off = flag_off;
+        d.kind = kinds ? kinds[k] : K_GAUSSIAN; d.D = D[k]; d.L = 0; d.flag_off = flag_off;
         flag_off += D[k];
         if (D[k] > e->Dmax) e->Dmax = D[k];
-        e->x[k].assign(data[k], data[k] + (size_t)n * D[k]);
-        d.xf = e->x[k].data();
-        e->gtab[k].resize((size_t)n + 1);
-        for (long long m = 0; m <= n; ++m) {
-            const double nn = (double)m;
-            e->gtab[k][m] = (log(1.0 / sqrt(M_PI)) + lgamma(0.5 * nn + 1.0)) - lgamma(0.5 * nn + 0.5);   // as pmdi_create
+        if (d.kind == K_GAUSSIAN) {
+            e->x[k].assign(data[k], data[k] + (size_t)n * D[k]);
+            d.xf = e->x[k].data();
+            e->gtab[k].resize((size_t)n + 1);
+            for (long long m = 0; m <= n; ++m) {
+                const double nn = (double)m;
+                e->gtab[k][m] = (log(1.0 / sqrt(M_PI)) + lgamma(0.5 * nn + 1.0)) - lgamma(0.5 * nn + 0.5);   // as pmdi_create
+            }
+            d.gtab = e->gtab[k].data();
+        } else {
+            // the host-built tables of pmdi_create (pmdi_api.cpp), restated
+            e->xi[k].resize((size_t)n * D[k]);
+            e->maxcol[k].assign(D[k], 0);
+            std::vector<long long> colsum(D[k], 0);
+            long long gmax = 0;
+            for (long long i = 0; i < n; ++i)
+                for (int q = 0; q < D[k]; ++q) {
+                    const long long v = (long long)data[k][(size_t)i * D[k] + q];
+                    e->xi[k][(size_t)i * D[k] + q] = (int)v;
+                    if (v > e->maxcol[k][q]) e->maxcol[k][q] = (int)v;
+                    if (v > gmax) gmax = v;
+                    colsum[q] += v;
+                }
+            d.xi = e->xi[k].data();
+            if (d.kind == K_CATEGORICAL) {
+                d.L = (int)gmax;
+                d.maxcol = e->maxcol[k].data();
+                e->lhtab[k].resize((size_t)(2 * n + gmax + 3));
+                for (size_t j = 0; j < e->lhtab[k].size(); ++j) e->lhtab[k][j] = log(0.5 * (double)j);
+                d.lhtab = e->lhtab[k].data();
+            } else {
+                long long smax = 0;
+                for (int q = 0; q < D[k]; ++q) if (colsum[q] > smax) smax = colsum[q];
+                const long long len = n + gmax + smax + 8;
+                e->lgtab[k].resize((size_t)len);
+                for (long long m = 0; m < len; ++m) e->lgtab[k][m] = lgamma((double)m);
+                d.lgtab = e->lgtab[k].data();
+                d.lgtab_len = len;
+            }
         }
-        d.gtab = e->gtab[k].data();
         d.stride = layout_arena(d, N, P, e->cap, n);
         e->arena[k].assign(d.stride, 0);
         d.arena = e->arena[k].data();
@@ -140,8 +178,9 @@ int emu_sweep(void *h, long long iter, const int *s_in, const int *order, long l
     std::vector<long long> wk(PMDI_KMAX_I * 8, 0);
     a.err = &err; a.cost = &cost; a.kstate = kstate.data(); a.work = wk.data();
     pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, a.s2);
-    RunArg r{&a, e->K, e->P / 256};
-    wavesim::run_block(256, 0, (size_t)a.s2.total, entry, &r);
+    const int nw = e->P > 1024 ? 8 : 4;
+    RunArg r{&a, e->K, e->P / (64 * nw), nw};
+    wavesim::run_block(64 * nw, 0, (size_t)a.s2.total, entry, &r);
     if (work) for (int k = 0; k < e->K; ++k) for (int j = 0; j < 8; ++j) work[k * 8 + j] = wk[k * 8 + j];
     if (err == 0 && particle) {
         // what pmdi_export_state does: expand the columns back to particle[n, p, k]

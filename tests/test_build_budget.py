@@ -51,7 +51,8 @@ def test_spill_budget_of_the_sweep_kernel_builds():
 
 
 SRC2 = os.path.join(ROOT, "particlemdi.jl_amd", "csrc", "pmdi_sweep2.hip")
-BUDGET2 = 90          # VGPR spill slots of any <K, PPL> build of the settled-chain kernel (256 registers, two workgroups per CU).
+BUDGET2 = 100         # VGPR spill slots of any <K, PPL, NW> build of the settled-chain kernel (256 registers, two waves per SIMD).
+#                       Round 4 (three cluster types, 4- and 8-wave workgroups) measures 24..99; <4, 4, 4> -- the headline's -- 69.
 #                       Round 3 measures 19..82: 0..25 until the statistics phase shared by all four waves (help_stats) was added -- it runs
 #                       with every lane's particle state live and costs ~55 slots (15 of the 40 scratch stores of <4, 4> are loop
 #                       invariants parked once before the sweep loop), and it still made the HL sweep 3 % faster (the slowest chains 10 %).
@@ -68,13 +69,14 @@ def test_spill_budget_of_the_settled_chain_kernel_builds():
     assert r.returncode == 0, r.stderr[-2000:]
     cur, seen = None, {}
     for line in r.stderr.splitlines():
-        m = re.search(r"Function Name: \S*pmdi_sweep2_kernelILi(\d)ELi(\d)E", line)
+        m = re.search(r"Function Name: \S*pmdi_sweep2_kernelILi(\d)ELi(\d)ELi(\d)E", line)
         if m:
-            cur = (int(m.group(1)), int(m.group(2)))
+            cur = (int(m.group(1)), int(m.group(2)), int(m.group(3)))
         m = re.search(r"VGPRs Spill: (\d+)", line)
         if m and cur:
             seen[cur] = int(m.group(1))
             cur = None
-    assert len(seen) == 12, sorted(seen)
+    assert len(seen) == 16, sorted(seen)
     for variant, n in seen.items():
-        assert n <= BUDGET2, f"pmdi_sweep2_kernel<{variant[0]}, {variant[1]}> spills {n} VGPRs (budget {BUDGET2})"
+        assert n <= BUDGET2, f"pmdi_sweep2_kernel<{variant[0]}, {variant[1]}, {variant[2]}> spills {n} VGPRs (budget {BUDGET2})"
+    assert seen[(4, 4, 4)] <= 75, seen[(4, 4, 4)]

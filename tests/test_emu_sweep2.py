@@ -15,12 +15,32 @@ def _gauss(rng, n, K, D=12, sep=3.0):
     return [rng.normal(size=(n, D + k)) + sep * (z[:, None] - 1) for k in range(K)], z
 
 
-def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0, variant=""):
+def _mixed(rng, n, kinds, sep=3.0):
+    """Datasets of the given cluster types sharing one planted 3-cluster structure."""
+    z = rng.integers(0, 3, n)
+    data = []
+    for j, kind in enumerate(kinds):
+        if kind == "gaussian":
+            data.append(rng.normal(size=(n, 9 + j)) + sep * (z[:, None] - 1))
+        elif kind == "categorical":      # levels 1..4, per-cluster level probabilities
+            pr = rng.dirichlet(0.5 * np.ones(4), size=(3, 7 + j))
+            x = np.empty((n, 7 + j), dtype=np.int64)
+            for q in range(7 + j):
+                for c in range(3):
+                    m = z == c
+                    x[m, q] = 1 + rng.choice(4, size=int(m.sum()), p=pr[c, q])
+            data.append(x)
+        else:                            # geometric counts with a per-cluster rate
+            data.append(rng.geometric(0.15 + 0.3 * z[:, None], size=(n, 6 + j)) - 1)
+    return data, z
+
+
+def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0, variant="", kinds=None):
     from _emu import EmuSweeper
     rng = np.random.default_rng(seed)
     n, K = data[0].shape[0], len(data)
-    kinds = ["gaussian"] * K
-    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant)
+    kinds = kinds or ["gaussian"] * K
+    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant, kinds=kinds)
     o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1)
     rec = o.debug_steps(n - n1 + 1)
     requeued = []
@@ -33,7 +53,7 @@ def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=
         order = rng.permutation(n) + 1
         Pi, Phi = random_hypers(rng, N, K)
         if settle:
-            Pi[:3] += 1.0; Pi /= Pi.sum(0)
+            Pi[:3] += float(settle); Pi /= Pi.sum(0)
         ro = o.sweep(it, s, order, n1, Pi, Phi, flags=flags, trace=True)
         re = e.sweep(it, s, order, n1, Pi, Phi, flags=flags, trace=True)
         if re["err"] == 1 and allow_requeue:       # the chain does not fit the settled-chain kernel at some step: the general kernel's job
@@ -64,15 +84,16 @@ def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=
     return rec
 
 
-def _chain(O, data, N, P, seed, burn, iters, q1=0, cols_l=64, idcap=128, allow_requeue=0, flags=None, variant=""):
+def _chain(O, data, N, P, seed, burn, iters, q1=0, cols_l=64, idcap=128, allow_requeue=0, flags=None, variant="", kinds=None):
     """A real Gibbs chain (the oracle's hyper-parameter updates): `burn` iterations on the oracle alone from the random start of
     src/pmdi.jl:63-66, then `iters` iterations swept by both."""
     from _emu import EmuSweeper
     n, K = data[0].shape[0], len(data)
     n1 = max(1, n // 4)
     hy = O.Hypers(n, N, K, seed=seed)
-    o = O.Oracle(data, ["gaussian"] * K, N, P, seed=seed, q1_mode=q1)
-    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant)
+    kinds = kinds or ["gaussian"] * K
+    o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1)
+    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant, kinds=kinds)
     rec = o.debug_steps(n - n1 + 1)
     requeued, compared = [], 0
     for it in range(1, burn + iters + 1):
@@ -119,6 +140,39 @@ def test_gibbs_chain_after_burn_in_equals_oracle(O, K, P, n, N):
     rng = np.random.default_rng(5)
     data, _ = _gauss(rng, n, K, D=10, sep=3.0)
     assert _chain(O, data, N, P, 7 + K, 6, 3, allow_requeue=1) >= 2
+
+
+MIXED = [("gaussian", "categorical"), ("categorical", "negbinom"), ("gaussian", "gaussian", "categorical", "negbinom"), ("negbinom",), ("categorical",)]
+
+
+@pytest.mark.parametrize("kinds", MIXED, ids=["+".join(k[:3] for k in ks) for ks in MIXED])
+def test_mixed_cluster_types_equal_oracle(O, kinds):
+    """Categorical and NegBinom datasets beside Gaussian ones (categorical_cluster.jl:29-51, negbinom_cluster.jl:22-51): integer
+    statistics, host-built log / loggamma tables -- allocations, log-weights, counters, exported state equal to the oracle's, from a
+    planted start and in a Gibbs chain after burn-in (clones, resampling, renumbering moves of the integer pool rows)."""
+    rng = np.random.default_rng(21)
+    data, z = _mixed(rng, 180, list(kinds))
+    _compare(O, data, 6, 256, 3, 300 + len(kinds), 45, settle=True, truth=z, allow_requeue=1, kinds=list(kinds), scramble=0.15)
+    assert _chain(O, data, 8, 256, 17 + len(kinds), 5, 3, allow_requeue=1, kinds=list(kinds)) >= 2
+
+
+def test_mixed_cluster_types_with_feature_flags_and_arena_tables(O):
+    rng = np.random.default_rng(22)
+    kinds = ["categorical", "gaussian", "negbinom"]
+    data, z = _mixed(rng, 160, kinds)
+    fl = [(rng.random(d.shape[1]) < 0.7).astype(np.uint8) for d in data]
+    _compare(O, data, 6, 512, 2, 77, 40, settle=True, truth=z, flags=fl, allow_requeue=1, kinds=kinds, cols_l=2, idcap=8, scramble=0.2)
+
+
+def test_eight_wave_workgroup_for_2048_particles(O):
+    """P = 2 048: a 512-thread workgroup (eight waves, four particles per lane; the first K waves own a dataset each, all eight share
+    the particle phases, the statistics phase and the resampling) -- mixed cluster types, N = 50 labels as in BASELINE config 4."""
+    rng = np.random.default_rng(23)
+    kinds = ["gaussian", "gaussian", "categorical", "negbinom"]
+    data, z = _mixed(rng, 120, kinds)
+    _compare(O, data, 50, 2048, 2, 91, 30, settle=200.0, truth=z, allow_requeue=0, kinds=kinds, scramble=0.1)
+    data, z = _gauss(rng, 120, 1, D=7)
+    _compare(O, data, 5, 2048, 2, 92, 30, settle=True, truth=z, allow_requeue=0)
 
 
 def test_arena_fallback_of_the_lds_tables(O):

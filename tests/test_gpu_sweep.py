@@ -372,6 +372,84 @@ def test_settled_chain_kernel_equals_oracle(pkg, O, monkeypatch, K, P, n, N):
     sw.close()
 
 
+def _mixed_planted(rng, n, kinds, sep=3.0):
+    """Datasets of the given cluster types sharing one planted 3-cluster structure (as tests/test_emu_sweep2.py)."""
+    z = rng.integers(0, 3, n)
+    data = []
+    for j, kind in enumerate(kinds):
+        if kind == "gaussian":
+            data.append(rng.normal(size=(n, 9 + j)) + sep * (z[:, None] - 1))
+        elif kind == "categorical":
+            pr = rng.dirichlet(0.5 * np.ones(4), size=(3, 7 + j))
+            x = np.empty((n, 7 + j), dtype=np.int64)
+            for q in range(7 + j):
+                for c in range(3):
+                    m = z == c
+                    x[m, q] = 1 + rng.choice(4, size=int(m.sum()), p=pr[c, q])
+            data.append(x)
+        else:
+            data.append(rng.geometric(0.15 + 0.3 * z[:, None], size=(n, 6 + j)) - 1)
+    return data, z
+
+
+@pytest.mark.parametrize("kinds,P,n,N,settle", [
+    (("gaussian", "categorical"), 1024, 400, 30, 30.0),                       # BASELINE config 3's shape
+    (("categorical", "negbinom"), 512, 300, 8, 1.0),
+    (("gaussian", "gaussian", "categorical", "negbinom"), 2048, 300, 50, 200.0),   # BASELINE config 4's shape: eight-wave workgroups
+    (("negbinom",), 256, 300, 6, 1.0),
+    (("gaussian", "gaussian"), 2048, 240, 12, 5.0),
+], ids=["cfg3-shape", "cat+nb", "cfg4-shape", "nb-alone", "P2048"])
+def test_settled_chain_kernel_mixed_types_equal_oracle(pkg, O, monkeypatch, kinds, P, n, N, settle):
+    """The settled-chain kernel on Categorical / NegBinom datasets beside Gaussian ones (categorical_cluster.jl:29-51,
+    negbinom_cluster.jl:22-51) and on 2 048 particles (512-thread workgroups): forced from the first sweep on planted chains; trace,
+    allocations, picked particle, log-weights, counters, work counters and exported state equal the oracle's; integer types bit-exact."""
+    monkeypatch.setenv("PMDI_SETTLED", "2")
+    monkeypatch.setenv("PMDI_KSPLIT", "0")
+    kinds = list(kinds)
+    K = len(kinds)
+    rng = np.random.default_rng(200 + K + P)
+    data, z = _mixed_planted(rng, n, kinds)
+    n1 = n // 4
+    C = 3
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=C, seed=901)
+    assert sw.settled
+    orcs = [O.Oracle(data, kinds, N, P, seed=901 + c) for c in range(C)]
+    recs = [o.debug_steps(n - n1 + 1) for o in orcs]
+    s = np.repeat(np.repeat((z + 1)[None, :, None], K, axis=2), C, axis=0)
+    idx = rng.random(s.shape) < 0.04
+    s[idx] = rng.integers(1, N + 1, size=int(idx.sum()))
+    all_int = all(k != "gaussian" for k in kinds)
+    for it in range(1, 4):
+        order = np.stack([rng.permutation(n) + 1 for _ in range(C)])
+        hyp = [random_hypers(rng, N, K) for _ in range(C)]
+        for h in hyp:
+            h[0][:3] += settle; h[0][:] = h[0] / h[0].sum(0)
+        rg = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]), trace=True)
+        wk = sw.work_counters()
+        for c in range(C):
+            ro = orcs[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1], trace=True)
+            bad = np.where(~np.isclose(rg["trace"][c], ro["trace"], rtol=1e-9, atol=1e-9).all(axis=1))[0]
+            assert bad.size == 0, f"chain {c} iteration {it}: first diverging swept observation {bad[0]}: gpu={rg['trace'][c][bad[0]]} cpu={ro['trace'][bad[0]]}"
+            assert (rg["s"][c] == ro["s"]).all() and int(rg["p_star"][c]) == ro["p_star"]
+            # (integer types: the log-predictives are the oracle's bits -- host-built tables, same order of additions; the increment's
+            # log(f[N]) is the device's log either way)
+            assert np.allclose(rg["logweight"][c], ro["logweight"], rtol=1e-12 if all_int else 1e-9, atol=1e-9 if all_int else 1e-8)
+            for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
+                assert rg["stats"][c][key] == ro["stats"][key], key
+            up, mv = orcs[c].work()
+            ev, cols, splits = expected_work_counters(recs[c], ro["trace"], N)
+            assert (wk[c][:, 1] == up).all() and (wk[c][:, 3] == mv).all() and (wk[c][:, 0] == ev).all()
+            assert (wk[c][:, 5] == cols).all() and (wk[c][:, 6] == splits).all()
+            eg, eo = sw.export_state(c), orcs[c].export()
+            assert (eg["particle"] == eo["particle"]).all() and (eg["max_id"] == eo["max_id"]).all()
+            t5_invariants(eg, N, P, K, n)
+            s[c] = ro["s"]
+    gb = sw.given_back()
+    print(f"{'+'.join(kinds)} P={P}: chains handed back (reachable, chosen, classes, total) = {gb.tolist()} of {3 * C} chain-sweeps")
+    assert gb[3] <= 2 * C
+    sw.close()
+
+
 def test_settled_chain_kernel_hands_back_what_does_not_fit(pkg, O, monkeypatch):
     """From the random start of src/pmdi.jl:63-66 a chain has dozens of particle classes (more than the sixteen the settled-chain
     kernel holds per dataset): forced onto that kernel it is handed back at once and the general kernel sweeps it: results equal the
