@@ -115,37 +115,47 @@ def oracle_chain(w, state, n_iter, seed, progress=False):
     return out
 
 
-def parity_check(pkg, w, g, sw, chain, seed, fsel):
-    """Outside the timed region: ONE more iteration of the device-resident chains, and chain `chain` of it re-run through the
-    oracle (the checker) from the same post-hyper-update state, same Philox key, same iteration number: allocations and the
-    picked particle must be equal, the log-weights within the north-star tolerance.  Returns the JSON fragment."""
+KERNEL_NAMES = {0: "general", 1: "settled-chain", 2: "general after a hand-back"}
+
+
+def parity_check(pkg, w, g, sw, chains, seed, fsel):
+    """Outside the timed region: ONE more iteration of the device-resident chains, and every chain of `chains` (label, index) of it
+    re-run through the oracle (the checker) from the same post-hyper-update state, same Philox key, same iteration number:
+    allocations, the picked particle and the five counters must be equal, the log-weights within the north-star tolerance.  Which
+    kernel swept each compared chain comes back with it (pmdi_chain_swept_by).  Returns the JSON fragment."""
     O = G.load_oracle()
     n, N, K, P = w["n"], w["N"], w["K"], w["P"]
     g.step(pkg.STEP_BEGIN); g.step(pkg.STEP_HYPERS)
-    st1 = g.get(chain)
+    before = {c: g.get(c) for _, c in chains}
     g.step(pkg.STEP_SWEEP)
     res = g.results()
-    s_dev = g.get(chain)["s"]                       # before the label alignment: s = sstar[p_star, :, :]
+    swept = sw.swept_by()
+    s_dev = {c: g.get(c)["s"] for _, c in chains}      # before the label alignment: s = sstar[p_star, :, :]
     if fsel:
         g.step(pkg.STEP_FEATSEL)
     g.step(pkg.STEP_ALIGN)
     it = g.iterations
-    Pi = st1["gamma"] / st1["gamma"].sum(axis=0, keepdims=True)
-    flags = [st1["flags"][sum(w["D"][:k]):sum(w["D"][:k + 1])] for k in range(K)]
-    orc = O.Oracle(w["data"], w["kinds"], N, P, seed=seed + chain)
-    ro = orc.sweep(it, st1["s"], st1["order"], g.n1, Pi, st1["Phi"], flags, lw_init=1.0)
-    orc.close()
-    same_s = bool((s_dev == ro["s"]).all())
-    same_p = int(res["p_star"][chain]) == int(ro["p_star"])
-    same_counters = all(int(res["stats"][chain, j]) == int(ro["stats"][key])
-                        for j, key in enumerate(("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")))
-    lw_ok = bool(np.allclose(res["logweight"][chain], ro["logweight"], rtol=1e-6, atol=1e-6))
-    ok = same_s and same_p and same_counters and lw_ok
-    return {"parity_check": "ok" if ok else "FAILED",
-            "parity_check_detail": {"chain": int(chain), "iteration": int(it), "allocations_equal": same_s, "p_star_equal": same_p,
-                                    "counters_equal": same_counters, "logweights_within_1e-6": lw_ok,
-                                    "oracle_sweep_seconds": float(ro["stats"]["seconds"]),
-                                    "note": "one timed-state chain re-run through the CPU oracle (checker only) outside the timed region"}}
+    detail, all_ok = [], True
+    for label, chain in chains:
+        st1 = before[chain]
+        Pi = st1["gamma"] / st1["gamma"].sum(axis=0, keepdims=True)
+        flags = [st1["flags"][sum(w["D"][:k]):sum(w["D"][:k + 1])] for k in range(K)]
+        orc = O.Oracle(w["data"], w["kinds"], N, P, seed=seed + chain)
+        ro = orc.sweep(it, st1["s"], st1["order"], g.n1, Pi, st1["Phi"], flags, lw_init=1.0)
+        orc.close()
+        same_s = bool((s_dev[chain] == ro["s"]).all())
+        same_p = int(res["p_star"][chain]) == int(ro["p_star"])
+        same_counters = all(int(res["stats"][chain, j]) == int(ro["stats"][key])
+                            for j, key in enumerate(("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes")))
+        lw_ok = bool(np.allclose(res["logweight"][chain], ro["logweight"], rtol=1e-6, atol=1e-6))
+        all_ok = all_ok and same_s and same_p and same_counters and lw_ok
+        detail.append({"which": label, "chain": int(chain), "kernel": KERNEL_NAMES.get(int(swept[chain]), "?"), "allocations_equal": same_s,
+                       "p_star_equal": same_p, "counters_equal": same_counters, "logweights_within_1e-6": lw_ok,
+                       "oracle_sweep_seconds": float(ro["stats"]["seconds"])})
+    return {"parity_check": "ok" if all_ok else "FAILED",
+            "parity_check_detail": {"iteration": int(it), "chains": detail,
+                                    "note": "timed-state chains (median cost, 99th percentile of cost, a chain of the last launch round) re-run through the "
+                                            "CPU oracle (checker only) outside the timed region; `kernel` = which device kernel swept the compared chain"}}
 
 
 def host_core_share():
@@ -320,6 +330,8 @@ def main():
     stats = res["stats"]
     work = sw.work_counters()
     costs = sw.chain_costs().astype(np.float64)               # shader cycles of every chain's last sweep
+    swept = sw.swept_by()                                     # ... and which kernel finished it
+    given_back = sw.given_back()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -369,6 +381,11 @@ def main():
             "per_chain_iters_per_sec": {"p50": float(1.0 / np.median(chain_s)), "slowest": float(1.0 / chain_s.max()),
                                         "fastest": float(1.0 / chain_s.min()),
                                         "note": "1 / (shader cycles of the chain's own sweep / shader clock), all chains co-resident"},
+            "kernels": {"settled_chain_kernel": bool(sw.settled),
+                        "chains_by_kernel_last_sweep": {KERNEL_NAMES[j]: int((swept == j).sum()) for j in (0, 1, 2)},
+                        "chain_seconds_p50_by_kernel": {KERNEL_NAMES[j]: (float(np.median(chain_s[swept == j])) if (swept == j).any() else None) for j in (0, 1, 2)},
+                        "handed_back_so_far": {"more_than_32_classes": int(given_back[1]), "more_than_16_classes_or_wide_ids": int(given_back[2]), "total": int(given_back[3])},
+                        "note": "pmdi_chain_swept_by / pmdi_settled_kernel: which device kernel finished each chain's last timed sweep"},
             "sweep_stats_last": {"ids_per_step": float(stats[:, 0].mean()) / (n_s * K),
                                  "classes_per_step": float(stats[:, 4].mean()) / (n_s * K),
                                  "resamples": float(stats[:, 1].mean()), "clones": float(stats[:, 2].mean()),
@@ -385,8 +402,8 @@ def main():
                                                               "compares with across rounds; the column table needs ~4x fewer bytes for the same work"},
                          "note": "achieved = de-duplication-aware algorithmic bytes of one sweep (built from the kernel's work counters: "
                                  "clusters evaluated / updated / cloned / moved, resampling events, per-step and per-sweep streams; "
-                                 "DESIGN.md section 6) / sweep time. traffic = PMC-measured HBM bytes per sweep of this operating point (profiles/hbm_traffic.json); since "
-                                 "round 3 it is BELOW the algorithmic bytes at HL (0.29 TB against 0.72 TB): the settled-chain kernel keeps the tables the model "
+                                 "DESIGN.md section 6) / sweep time. traffic = PMC-measured HBM bytes per sweep of this operating point (profiles/hbm_traffic.json; "
+                                 "null when that operating point has no counter pass); where it is BELOW the algorithmic bytes (HL since round 3) the settled-chain kernel keeps the tables the model "
                                  "prices as memory traffic in LDS and registers (profiles/README.md). dense_model_ratio = SURVEY 8d's dense-model bytes / these: the work "
                                  "the reference's de-duplication (kept here) avoids. A sweep is bound by dependent latency, not by HBM."},
         }
@@ -396,7 +413,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and not args.no_parity and args.workload != "cfg5":
         # ---- parity of the timed kernel instantiation, outside the timed region (cfg5: the oracle needs minutes per sweep)
-        out.update(parity_check(pkg, w, g, sw, int(np.argsort(costs)[C // 2]), seed, False))
+        by_cost = np.argsort(costs)
+        last_round = int(sw.launch_order()[-1]) if hasattr(sw, "launch_order") else int(by_cost[0])
+        picks = [("median cost", int(by_cost[C // 2])), ("99th percentile of cost", int(by_cost[min(C - 1, int(0.99 * C))])), ("last launch round", last_round)]
+        out.update(parity_check(pkg, w, g, sw, picks, seed, False))
         if out["parity_check"] != "ok":
             print(json.dumps(out))
             raise SystemExit("bench: the timed kernel's results differ from the oracle's: " + json.dumps(out["parity_check_detail"]))

@@ -330,12 +330,19 @@ int pmdi_chain_costs(pmdi_handle *h, int64_t *out);
 int pmdi_work_counters(pmdi_handle *h, int64_t *out);
 
 /* 1 when the handle's light chains (few live clusters per step: what a chain looks like after its first iterations) are swept by
- * the settled-chain kernel (csrc/pmdi_sweep2.hip: all-Gaussian configurations, K <= 4, N <= 64, D <= 64, P in {256, 512, 1024},
- * default quirk modes, one workgroup per chain; PMDI_SETTLED=0 switches it off), else 0.  given_back4 (optional, 4 Int64): chains
- * that kernel has handed back to the general kernel so far because a step outgrew its tables -- [0] unused (0:
- * any number of reachable clusters is evaluated in place), [1] of [2]: more than 16 particle classes, [2] more than 8 particle classes, [3] in total.  A handed-back
- * chain is swept again from the start of the same sweep by the general kernel: results never depend on which kernel ran. */
+ * the settled-chain kernel (csrc/pmdi_sweep2.hip: any mix of Gaussian / Categorical / NegBinom datasets, K <= 4, N <= 64, D <= 64,
+ * P in {256, 512, 1024, 2048}, default quirk modes, one workgroup per chain; PMDI_SETTLED=0 switches it off), else 0.
+ * given_back4 (optional, 4 Int64): chains that kernel has handed back to the general kernel so far because a step outgrew its
+ * tables -- [0] unused (always 0: any number of reachable clusters is evaluated in place); [1] steps with more than 32 particle
+ * classes in a dataset (a subset of [2]); [2] steps with more than 16 particle classes in a dataset, or cluster ids beyond 16 bits;
+ * [3] in total.  A handed-back chain is swept by the general kernel inside the same call: allocations, picked particle and
+ * counters never depend on which kernel ran (the traced ESS agrees to ~1e-13: tree-ordered sums). */
 int pmdi_settled_kernel(pmdi_handle *h, int64_t *given_back4);
+
+/* out[n_chains]: which kernel finished each chain's LAST sweep -- 0 the general kernel (csrc/pmdi_sweep.hip), 1 the settled-chain
+ * kernel, 2 the general kernel after the settled-chain kernel had handed the chain back in that sweep.  Diagnostics: the parity
+ * tests and bench.py's parity_check use it to say which kernel the compared chains ran on. */
+int pmdi_chain_swept_by(pmdi_handle *h, int32_t *out);
 
 int pmdi_sum_D(const pmdi_handle *h);
 int pmdi_block_threads(const pmdi_handle *h);   /* threads per chain workgroup */

@@ -35,7 +35,7 @@ EXPORTS = [
     "pmdi_csv_open", "pmdi_csv_write_row", "pmdi_csv_write_gibbs", "pmdi_csv_open_features", "pmdi_csv_write_flags",
     "pmdi_csv_close", "pmdi_csv_read_allocations", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz", "pmdi_is_split",
     "pmdi_comm_unique_id", "pmdi_comm_init_rank", "pmdi_comm_init_all", "pmdi_comm_destroy", "pmdi_comm_rank", "pmdi_comm_size",
-    "pmdi_allgather_samples", "pmdi_settled_kernel",
+    "pmdi_allgather_samples", "pmdi_settled_kernel", "pmdi_chain_swept_by",
 ]
 
 
@@ -184,6 +184,8 @@ def lib():
     L.pmdi_is_split.argtypes = [vp]
     L.pmdi_settled_kernel.restype = C.c_int
     L.pmdi_settled_kernel.argtypes = [vp, vp]
+    L.pmdi_chain_swept_by.restype = C.c_int
+    L.pmdi_chain_swept_by.argtypes = [vp, vp]
     L.pmdi_shader_clock_hz.restype = i64
     L.pmdi_shader_clock_hz.argtypes = [vp]
     L.pmdi_work_counters.restype = C.c_int
@@ -356,10 +358,17 @@ class Sweeper:
         return out.cpu().numpy().astype(np.int64)
 
     def given_back(self):
-        """Chains the settled-chain kernel has handed back to the general kernel so far: (reachable clusters, chosen clusters,
-        particle classes, total)."""
+        """Chains the settled-chain kernel has handed back to the general kernel so far (include/pmdi_hip.h, pmdi_settled_kernel):
+        [0] unused (0), [1] steps with more than 32 particle classes (a subset of [2]), [2] more than 16 particle classes or cluster
+        ids beyond 16 bits, [3] total."""
         out = np.zeros(4, dtype=np.int64)
         lib().pmdi_settled_kernel(self.h, _ptr(out))
+        return out
+
+    def swept_by(self):
+        """Which kernel finished each chain's last sweep: 0 general, 1 settled-chain, 2 general after a hand-back."""
+        out = np.zeros(self.C, dtype=np.int32)
+        _check(lib().pmdi_chain_swept_by(self.h, _ptr(out)))
         return out
 
     def chain_costs(self):

@@ -85,7 +85,7 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
         d.o_particle[0] = take((size_t)N * P * 4);
         d.o_particle[1] = take((size_t)N * P * 4);
         d.o_col = take((size_t)P * 4);
-        d.o_cgrp = take((size_t)N * P * 8);
+        d.o_cgrp = take((size_t)(N > 3 ? N : 3) * P * 8);      // (the settled-chain kernel keeps 20 bytes per column there: N = 2 would not hold them)
         d.o_pid = take((size_t)P * 4);
         d.o_sid = take((size_t)P * 4);
         d.o_kv = take((size_t)P * 4);
@@ -99,6 +99,7 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
         d.o_clsval = take((size_t)P * 4);
         d.o_cdf = take((size_t)P * (N + 2) * 8);
         d.o_dl = take((size_t)3 * P * 4);
+        d.o_s2x = take((size_t)2048 * 12);
     }
     d.o_cn = take(ids * 4);
     if (d.kind == K_GAUSSIAN) {
@@ -145,6 +146,9 @@ struct pmdi_handle {
     std::vector<void *> owned;          // device allocations freed in destroy
     // per-call staging (device)
     DevBuf d_s_in, d_order, d_Pi, d_logphi, d_flags, d_s_out, d_lw, d_pstar, d_stats, d_err, d_trace;
+    DevBuf d_swept_by, d_resume;
+    bool s2_continue = true;     // a chain the settled-chain kernel gives back is carried on by the general kernel at that observation
+                                 // (false: swept again from the start -- the round-3 behaviour, kept for A/B runs)
     DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_args4, d_args5, d_requeue, d_requeue_total, d_handed, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
     int ksplit = 0;
     int ksplit_batch = 0;        // split mode: chain slots per launch when n_chains * K workgroups are not resident at once (0 = one launch)
@@ -236,6 +240,8 @@ void fill_sweep_common(const pmdi_handle *h, SweepArgs &a)
     a.requeue_total = h->s2_ok ? (long long *)h->d_requeue_total.p : nullptr;
     a.handed = h->s2_ok ? (int *)h->d_handed.p : nullptr;
     a.sweep_no = h->sweep_no;
+    a.swept_by = (int *)h->d_swept_by.p;
+    a.resume = (h->s2_ok && h->s2_continue) ? (int *)h->d_resume.p : nullptr;
     a.n = h->cfg.n;
     a.seed = h->cfg.seed;
     for (int k = 0; k < h->cfg.K; ++k) a.ds[k] = h->ds[k];
@@ -341,13 +347,19 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (settled chains): %s", hipGetErrorString(e));
             SweepArgs ar = al;
             ar.group_flag = nullptr; ar.requeue_only = 1;
-            // ... with one workgroup per dataset when the model has several (the latency form: a chain that is swept twice should at
-            // least be swept fast the second time -- it is the tail of the whole sweep)
-            if (h->cfg.K > 1 && h->d_xcnt.p && !(getenv("PMDI_REQUEUE_KSPLIT") && atoi(getenv("PMDI_REQUEUE_KSPLIT")) == 0)) {
+            int Tr = 256;
+            if (h->s2_continue) {
+                // ... from the observation where that kernel stopped (its hand-over record): one workgroup per chain -- the wide build
+                // when a lane of the 256-thread one would carry eight particles
+                ar.resume_mode = 1;
+                if (h->cfg.P > 1024) { Tr = h->T; ar.terms_cap = h->terms_cap; ar.pid_lds = h->pid_lds; ar.pp_lds = h->pp_lds; ar.col_lds = h->col_lds; }
+            } else if (h->cfg.K > 1 && h->d_xcnt.p && !(getenv("PMDI_REQUEUE_KSPLIT") && atoi(getenv("PMDI_REQUEUE_KSPLIT")) == 0)) {
+                // ... from the start, with one workgroup per dataset when the model has several (the latency form: a chain that is swept
+                // twice should at least be swept fast the second time -- it is the tail of the whole sweep)
                 ar.ksplit = 1;
                 HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, h->stream2));
             }
-            e = launch_one(h, ar, (SweepArgs *)h->d_args5.p, C, 256, h->stream2);
+            e = launch_one(h, ar, (SweepArgs *)h->d_args5.p, C, Tr, h->stream2);
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (chains given back by the settled-chain kernel): %s", hipGetErrorString(e));
         } else {
             e = launch_maybe_batched(h, al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
@@ -390,7 +402,7 @@ int pmdi_destroy(pmdi_handle *h)
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
                       &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_args4, &h->d_args5, &h->d_requeue, &h->d_requeue_total, &h->d_handed, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
-                      &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
+                      &h->d_swept_by, &h->d_resume, &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
@@ -619,11 +631,18 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 if (cols_l > P) cols_l = P;
                 if (idcap < 8) idcap = 8;
                 if (idcap > 4096) idcap = 4096;
-                pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
+                // particle classes per dataset the LDS tables hold: as many as the budget allows, 32 at most (a step with more hands the
+                // chain over to the general kernel: with N labels a single ambiguous observation fans one class out into up to N)
+                int cls = env_int("PMDI_S2_CLS", 32);
+                if (cls < 16) cls = 16;
+                if (cls > 32) cls = 32;
+                cls &= ~3;
+                pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, &h->s2);
+                while ((size_t)h->s2.total > budget && cls > 16) { cls -= 4; pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, &h->s2); }
                 while ((size_t)h->s2.total > budget && (cols_l > 16 || idcap > 64)) {
                     // (a settled chain holds 6-40 columns and ids below ~40 at the 99th percentile of its steps: the id tables go first)
                     if (idcap > 96) idcap -= 16; else if (cols_l > 32) cols_l -= 8; else if (idcap > 64) idcap -= 16; else cols_l -= 8;
-                    pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, &h->s2);
+                    pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, &h->s2);
                 }
                 ok = (size_t)h->s2.total <= budget;
             }
@@ -637,7 +656,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         // in the general kernel -- but a K = 1 chain that never resamples keeps thousands of private clusters, and those steps belong to
         // the general kernel's hash tables: cfg2 with every chain light took 3.4 s per sweep instead of 0.8).  Without it: 40.
         h->light_ids = env_int("PMDI_LIGHT_IDS", h->s2_ok ? h->s2.idcap : 40);
+        if (h->s2_ok && env_int("PMDI_SETTLED", 1) == 2) h->light_ids = 1LL << 40;      // (tests: every chain starts every sweep on the settled-chain kernel)
         h->sticky = env_int("PMDI_STICKY", 3);
+        h->s2_continue = env_int("PMDI_CONTINUE", 1) != 0;
         if (h->split) {
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
         }
@@ -678,8 +699,10 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)) ||
         (rc = h->d_args4.ensure(sizeof(SweepArgs))) || (rc = h->d_args5.ensure(sizeof(SweepArgs))) || (rc = h->d_requeue.ensure((size_t)C * 4)) ||
-        (rc = h->d_requeue_total.ensure(4 * 8)) || (rc = h->d_handed.ensure((size_t)C * 4)))
+        (rc = h->d_requeue_total.ensure(4 * 8)) || (rc = h->d_handed.ensure((size_t)C * 4)) || (rc = h->d_swept_by.ensure((size_t)C * 4)) ||
+        (rc = h->d_resume.ensure((size_t)C * 16 * 4)))
         return bail(rc);
+    if (hipMemset(h->d_swept_by.p, 0, (size_t)C * 4) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));
     {
         std::vector<int> never((size_t)C, -1000);
         if (hipMemcpy(h->d_handed.p, never.data(), (size_t)C * 4, hipMemcpyHostToDevice) != hipSuccess) return bail(fail(PMDI_E_DEVICE, "memcpy failed"));
@@ -796,6 +819,14 @@ int pmdi_settled_kernel(pmdi_handle *h, int64_t *given_back4)
         }
     }
     return h->s2_ok ? 1 : 0;
+}
+int pmdi_chain_swept_by(pmdi_handle *h, int32_t *out)
+{
+    if (!h || !out) return fail(PMDI_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, h->d_swept_by.p, (size_t)h->cfg.n_chains * 4, hipMemcpyDeviceToHost));
+    return PMDI_OK;
 }
 int64_t pmdi_pool_cap(const pmdi_handle *h) { return h ? h->cap : 0; }
 int pmdi_categorical_L(const pmdi_handle *h, int32_t k) { return (h && k >= 0 && k < h->cfg.K) ? h->ds[k].L : 0; }

@@ -68,6 +68,7 @@ struct DsetDev {
     size_t o_clsval;        // int  [P]   class slot -> class value
     size_t o_cdf;           // double [P][N+2]  per class slot: CDF, log-increment, one-hot label or -1
     size_t o_dl;            // int  [3][P]  distinct chosen ids this step: src, dst, new n
+    size_t o_s2x;           // settled-chain kernel: log-predictives (double [2048]) and ids (int [2048]) of the reachable clusters beyond its LDS list
 };
 
 // LDS layout of the settled-chain kernel (pmdi_sweep2_body.h: make_layout fills it on the host, the kernel reads it from the
@@ -81,6 +82,7 @@ struct S2Layout {
     int tab, cmask, wmask, cbi, counts, cn, ncop, firstp, tgt, slotmap, ta, tax, lp, slot_id, slot_cn, slot_g, clsval, clslead, leadcol,
         minp, nidv, knew, itemj, clist, klist, kval, krep, bmc, bmf, cbm, kbm, xid, dsc;
     int Dp, cols_l, idcap, total;
+    int cls, kcap;          // particle classes per dataset the tables hold (16 .. 32); touched (class, label) keys per step the key lists hold
 };
 
 struct SweepArgs {
@@ -139,6 +141,12 @@ struct SweepArgs {
     int requeue_only;           // 1: this launch of the general kernel sweeps exactly those chains
     int slot_base;              // split mode launched in residency-sized batches: first chain slot of this launch
     int err_keep;               // 1: a successful sweep leaves err[chain] as it is (device-resident chains: the first error sticks)
+    int *resume;                // [chain][16] hand-over record of the settled-chain kernel: [0] position of the observation whose step did
+                                // not fit its tables, [1] mask of the datasets whose step of that observation is done, [2 + k] live columns
+                                // of dataset k; null: no continuation (a given-back chain is swept again from the start)
+    int resume_mode;            // 1: this launch of the general kernel carries on the given-back chains from their hand-over records
+    int *swept_by;              // [chain] which kernel finished the chain's last sweep: 0 general kernel, 1 settled-chain kernel,
+                                // 2 general kernel after the settled-chain kernel gave the chain back; or null
 };
 
 struct ClusterBatchArgs {
@@ -200,7 +208,7 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
 // workgroups of the sweep kernel build (T threads, the argument block's LDS layout) that one CU holds at once
 hipError_t pmdi_sweep_blocks_per_cu(const SweepArgs &a, int T, int *blocks);
 // the settled-chain kernel (pmdi_sweep2.hip)
-void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, S2Layout *L);
+void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, S2Layout *L);
 bool pmdi_sweep2_supports(int K, int N, int P, int Dmax, long long cap);
 int pmdi_sweep2_threads(int K, int P);      // threads of the workgroup that sweeps a chain of P particles (0: no build for it)
 hipError_t pmdi_sweep2_blocks_per_cu(const SweepArgs &a, int *blocks);

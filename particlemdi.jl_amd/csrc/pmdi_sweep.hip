@@ -517,6 +517,48 @@ __device__ PMDI_COLD_PREFIX void sweep_prefix(const SweepArgs *__restrict__ ap)
 
 }
 
+// A chain the settled-chain kernel (pmdi_sweep2_body.h, hand_over) gave up at some observation: instead of the reset and the known
+// prefix, the state of the chain as that kernel left it in the arena -- log-weights, column and class of every particle, counters,
+// per-dataset scalars -- and the class lists rebuilt from the particles' classes (leader = lowest particle: src/pmdi.jl:225-248).
+template <int T>
+__device__ __noinline__ void sweep_resume_load(const SweepArgs *__restrict__ ap)
+{
+    PMDI_PREAMBLE;
+    if (tid == 0) { PMDI_BUILD_LEAF_PROGRAM(); }
+    const int *rec = a.resume + (size_t)chain * 16;
+    for (int p = tid; p < P; p += T) sh.lw[p] = usc[p];
+    for (int k = 0; k < K; ++k) {
+        const DsetDev &d = dsb[k];
+        const KS s = make_ks(d, chain);
+        const int D = d.D;
+        const auto pidk = dual(a.pid_lds != 0, sh.pid + (size_t)k * P, s.pid);
+        const auto colk = dual(a.col_lds != 0, sh.col + (size_t)k * P, s.col);
+        unsigned char *flk = gen(sh.fl + (size_t)k * Dp);
+        if (a.pid_lds) for (int p = tid; p < P; p += T) sh.pid[(size_t)k * P + p] = s.pid[p];
+        if (a.col_lds) for (int p = tid; p < P; p += T) sh.col[(size_t)k * P + p] = s.col[p];
+        // (the settled-chain kernel keeps its per-column masks where the copy-on-write split keeps its step-tagged scratch)
+        for (int idx = tid; idx < N * P; idx += T) s.cgrp[idx] = 0;
+        for (int q = tid; q < D; q += T) flk[q] = flags ? flags[d.flag_off + q] : (unsigned char)1;
+        for (int nn = tid; nn < N; nn += T) sh.pis[k * N + nn] = Pi[(size_t)k * N + nn];
+        __syncthreads();
+        if (tid == 0) {
+            sh.kmaxid[k] = a.kstate[((size_t)chain * PMDI_KMAX_I + k) * 2];
+            sh.kcur[k] = 0;
+            sh.kncol[k] = rec[2 + k];
+            int nf = 0;
+            for (int q = 0; q < D; ++q) nf += flk[q];
+            sh.knflag[k] = nf;
+        }
+        const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
+        const int ncls = rebuild_classes<T>(pidk, cl, sh, P);
+        if (tid == 0) sh.kncls[k] = ncls;
+        __syncthreads();
+    }
+    if (tid < 6) sh.stat[tid] = a.stats[(size_t)chain * 8 + tid];
+    if (a.work && tid < K * 8) sh.wk[tid] = a.work[((size_t)chain * PMDI_KMAX_I) * 8 + tid];
+    __syncthreads();
+}
+
 // The fallback step's list of distinct chosen clusters, (src id, updated id, new n) per entry.  The
 // fast path's tables are idle during a fallback step, so the list lives in two LDS regions of theirs
 // (need .. dl: 8 * item_cap + 3 * PMDI_DL_LDS ints, contiguous; fl_p .. fl_tgt: 4 * PMDI_HT_SIZE ints)
@@ -756,7 +798,7 @@ __device__ PMDI_COLD_SLOW void sweep_slow(const SweepArgs *__restrict__ ap, int 
     int nd = 0, nclone = 0, new_ncls = 0, failed = 0;
     (void)items;
     if (converted) {
-                    for (int w = tid; w < items; w += T) sh.ktab_minp[w] = PMDI_INF_I;
+                    for (int w = tid; w < items && w < a.item_cap; w += T) sh.ktab_minp[w] = PMDI_INF_I;
                     for (int e = tid; e < H; e += T) { sh.h2.key[e] = 0; sh.h2.a[e] = 0; sh.h2.b[e] = PMDI_INF_I; }
                     for (int pb = 0; pb < P; pb += T) {
                         const int p = pb + tid;
@@ -1324,6 +1366,7 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
                 int *gc = (int *)(dsb[k].arena + (size_t)chain * dsb[k].stride + dsb[k].o_col);
                 for (int p = tid; p < P; p += T) gc[p] = (int)sh.col[(size_t)k * P + p];
             }
+        if (tid == 0 && kd0 == 0 && a.swept_by) a.swept_by[chain] = a.requeue_only ? 2 : 0;
         if (tid < K) {
             a.kstate[((size_t)chain * PMDI_KMAX_I + kd0 + tid) * 2] = sh.kmaxid[tid];
             a.kstate[((size_t)chain * PMDI_KMAX_I + kd0 + tid) * 2 + 1] = sh.kcur[tid];
@@ -1406,12 +1449,25 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     for (int e = tid; e < a.item_cap; e += T) sh.ktab_minp[e] = PMDI_INF_I;
     for (int e = tid; e < 2 * ((P >> 6) + 1); e += T) { sh.bm_fresh[e] = 0; sh.bm_clone[e] = 0; sh.bm_keep[e] = 0; sh.bm_reuse[e] = 0; }
 
+    // a chain the settled-chain kernel handed over carries on at the observation where that kernel stopped: the bookkeeping of the
+    // datasets it left undone is replayed from the recorded draws, then calc_ESS of that observation and everything after it
+    const bool resuming = a.resume_mode != 0 && a.resume != nullptr;
+    long long pos0 = n1 - 1;
+    int replay_done = 0;
+    bool replay = false;
+    if (resuming) {
+        __syncthreads();
+        sweep_resume_load<T>(ap);
+        pos0 = a.resume[(size_t)chain * 16];
+        replay_done = a.resume[(size_t)chain * 16 + 1];
+        replay = true;
+    } else
     sweep_prefix<T>(ap);
     // ---- the sweep: src/pmdi.jl:209-342 ----
     PH(1);
     int failed = 0;
-    bool lw_uniform = true;     // every particle holds the same log-weight (then ESS == P exactly)
-    int i_next = order[n1 - 1];
+    bool lw_uniform = !resuming;     // every particle holds the same log-weight (then ESS == P exactly)
+    int i_next = order[pos0];
     double nx = 0.0;          // register-staged observation row of the upcoming step
     int nxi = 0;
     int ns0_next = s_in[i_next];   // ... and the reference trajectory's label there (dataset 0)
@@ -1421,7 +1477,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             if (d0.kind == K_GAUSSIAN) nx = glob(d0.xf)[(size_t)i_next * d0.D + tid]; else nxi = glob(d0.xi)[(size_t)i_next * d0.D + tid];
         }
     }
-    for (long long pos = n1 - 1; pos < n && !failed; ++pos) {
+    for (long long pos = pos0; pos < n && !failed; ++pos) {
         int xhdr = 0;          // split mode: this step's hand-off is its header alone (bit 0), its one-hot label (bits 8..15)
         const int i = i_next;
         if (pos + 1 < n) i_next = order[pos + 1];
@@ -1449,6 +1505,35 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             const int items = ncls * N;
             const bool small = items <= a.item_cap;
             if (ncls != 1) lw_uniform = false;
+            if (replay) {
+                // the first observation of a handed-over chain: its labels are drawn and recorded (:265), the increments and the Phi term
+                // are in the log-weights.  A dataset whose step the settled-chain kernel finished is done; the others still need the
+                // step's bookkeeping -- class ids (:266-272), copy-on-write (:275-310) -- which is what the fallback step does with
+                // draws it did not make itself (`converted`)
+                if (!((replay_done >> k) & 1)) {
+                    for (int q = tid; q < D; q += T) {
+                        if (d.kind == K_GAUSSIAN) sh.xs[q] = glob(d.xf)[(size_t)i * D + q]; else ((int *)sh.xs)[q] = glob(d.xi)[(size_t)i * D + q];
+                    }
+                    for (int p = tid; p < P; p += T) sh.news[k * P + p] = s.sstar[(size_t)pos * P + p];
+                    for (int r = tid; r < ncls; r += T) sh.slot_of[cl.val(r)] = r;
+                    if (tid == 0) sh.misc[M_OVF] = 0;
+                    __syncthreads();
+                    sweep_slow<T, WPS>(ap, k, i, pos, false, true, maxid, ncls, ph_last, ph_cur);
+                    if (sh.misc[M_FAIL]) { failed = 1; break; }
+                    if (tid == 0) {
+                        const int nclone_r = sh.misc[M_NCLONE];
+                        sh.stat[7] += 1;
+                        sh.stat[0] += maxid;                  // src/__pmdi.jl:187
+                        sh.stat[4] += ncls;
+                        sh.stat[2] += nclone_r;
+                        if (maxid + nclone_r > sh.stat[3]) sh.stat[3] = maxid + nclone_r;
+                        sh.kmaxid[k] = maxid + nclone_r; sh.kncls[k] = sh.misc[M_NCLS];
+                        sh.wk[k * 8 + WK_UPD] += sh.misc[M_ND]; sh.wk[k * 8 + WK_CLONE] += nclone_r;
+                    }
+                    __syncthreads();
+                }
+                continue;
+            }
 
             PH(1);
             const int ns0_cur = ns0_next;
@@ -2025,6 +2110,19 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 
         // -- Phi_upweight! (src/misc.jl:50-59)
         PH(9);
+        if (replay) {
+            // (the settled-chain kernel added it; the next step's observation row and reference label, which a step fetches for its successor)
+            replay = false;
+            lw_uniform = false;
+            const DsetDev &d0 = dsb[0];
+            if (pos + 1 < n) {
+                if (tid < d0.D) {
+                    if (d0.kind == K_GAUSSIAN) nx = glob(d0.xf)[(size_t)i_next * d0.D + tid]; else nxi = glob(d0.xi)[(size_t)i_next * d0.D + tid];
+                }
+                ns0_next = s_in[i_next];
+            }
+            __syncthreads();
+        } else
         if (XSPLIT) {
             // Hand-off between the K workgroups of the chain (one per swept observation): every workgroup has stored its dataset's
             // records with agent-scope (sc1, write-through) stores; each storing wave drains them, the workgroup meets, one lane
@@ -2177,7 +2275,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     PH(11);
     sweep_final<T>(ap);
     PH(12);
-    if (tid == 0 && kd0 == 0) a.cost[chain] = clock64() - t_start;
+    if (tid == 0 && kd0 == 0) a.cost[chain] = (resuming ? a.cost[chain] : 0) + (clock64() - t_start);
     if (a.phase && tid == 0) {
         sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0;
     }

@@ -46,9 +46,9 @@ const void *kernel_for(int K, int P, int *nw)
 
 }  // namespace
 
-void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, S2Layout *L)
+void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, S2Layout *L)
 {
-    pmdi_s2::make_layout(K, N, P, Dmax, cols_l, idcap, *L);
+    pmdi_s2::make_layout(K, N, P, Dmax, cols_l, idcap, cls, *L);
 }
 
 int pmdi_sweep2_threads(int K, int P)

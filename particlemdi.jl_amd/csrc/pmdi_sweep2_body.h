@@ -208,10 +208,12 @@ constexpr int XR = 4;           // uncached clusters evaluated per round (their 
 #endif
 constexpr int XCAP = PM2_XCAP;  // uncached reachable clusters whose list entry and log-predictive live in LDS (the rest: arena)
 constexpr int NR = NS;          // term rows per dataset
-constexpr int CLS = 16;         // particle classes per dataset at most (beyond: requeue)
-constexpr int CSB = 4;          // bits of a class slot in the per-lane register word
-constexpr int RI_CLSMIN = 64, RI_NEWSLOT = 80, RI_CLSVAL = 96;      // resampling: per-class scratch, int offsets into the reduction area
-constexpr int RI_WCNT = 112;                                         // ... and per-wave counts of the block scans (NWMAX ints)
+constexpr int CLSMAX = 32;      // particle classes per dataset the class slots of a lane can name; how many of them a handle's LDS
+                                // tables hold (16 .. 32, Layout::cls) is the host's choice for the LDS budget.  A step with more: hand-over
+constexpr int CSB = 5;          // bits of a class slot in the per-lane register word
+constexpr int KCAPMAX = 256;    // (class, label) keys a step may touch at most (the key lists of the bookkeeping phase; Layout::kcap)
+constexpr int RI_CLSMIN = 64, RI_NEWSLOT = 96, RI_CLSVAL = 128;     // resampling: per-class scratch (CLSMAX ints each), int offsets into the reduction area
+constexpr int RI_WCNT = 160;                                         // ... and per-wave counts of the block scans (NWMAX ints)
 constexpr int RD_MAX = 0, RD_MIN = NWMAX, RD_SA = 2 * NWMAX, RD_SQ = 3 * NWMAX;      // doubles of the reduction area: per-wave maxima, minima, sums
 constexpr int KMAX2 = 4;        // datasets (one owner wave each)
 constexpr int NONE8 = 0xFF;
@@ -219,19 +221,22 @@ constexpr unsigned INFU = 0xFFFFFFFFu;
 constexpr int PMDI_S2_REQUEUE = 1;   // err code: sweep this chain again with the general kernel
 
 // per-dataset scalars (ints in LDS)
-enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_NDX, DS_ND, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_FOLLOW, DS_DIRTY, DS_NEEDMASK, DS_CHANGED, DS_NDLOW, DS_COUNT = 16 };
+enum { DS_MAXID = 0, DS_NCLS, DS_NCOL, DS_NDX, DS_ND, DS_NS0, DS_NX, DS_NNEED, DS_NCLONE, DS_NFLAG, DS_FOLLOW, DS_DIRTY, DS_NEEDMASK, DS_CHANGED, DS_NDLOW, DS_HALT, DS_COUNT = 16 };
 // shared scalars
 enum { SC_FAIL = 0, SC_RES, SC_PSTAR, SC_NLEAF, SC_NPROG, SC_JS, SC_TMP0, SC_TMP1, SC_TMP2, SC_TMP3, SC_COUNT = 16 };
 
 typedef S2Layout Layout;   // byte offsets into the workgroup's LDS: computed on the host (make_layout), read from the argument block
 
-PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, Layout &L)
+PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, Layout &L)
 {
+    const int CLS = cls;                                                   // particle classes per dataset the tables hold
+    const int kcap = (CLS * N < KCAPMAX) ? CLS * N : KCAPMAX;              // touched (class, label) keys per step the key lists hold
+    L.cls = cls; L.kcap = kcap;
     int o = 0;
     auto take = [&](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };
     const int Dp = (Dmax + 1) & ~1;
     L.Dp = Dp; L.cols_l = cols_l; L.idcap = idcap;
-    L.red = take(128 * 8);       // reductions: doubles [0,32) per-wave maxima / minima / sums (RD_*), ints [64,120) resampling scratch (RI_*), doubles [120] tie, [121] carry
+    L.red = take(128 * 8);       // reductions: doubles [0,32) per-wave maxima / minima / sums (RD_*), ints [64,168) resampling scratch (RI_*), doubles [120] tie, [121] carry
     L.sc = take(SC_COUNT * 4);
     L.stat = take(8 * 8);
     L.wk = take(KMAX2 * 8 * 8);
@@ -267,7 +272,7 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, La
     L.slot_id = take(NS * 4); L.slot_cn = take(NS * 4); L.slot_g = take(NS * 8);
     L.clsval = take(CLS * 4); L.clslead = take(CLS * 4); L.leadcol = take(CLS * 4);
     L.minp = take(CLS * N * 4); L.nidv = take(CLS * N * 2); L.knew = take(CLS * N); L.itemj = take(CLS * N * 2);
-    L.clist = take(idcap * 2); L.klist = take(CLS * N * 2); L.kval = take(CLS * N * 2); L.krep = take(CLS * N);
+    L.clist = take(idcap * 2); L.klist = take(kcap * 2); L.kval = take(kcap * 2); L.krep = take(kcap);
     L.bmc = take((P / 64 + 1) * 8); L.bmf = take((P / 64 + 1) * 8);
     L.cbm = take(((idcap + 63) / 64) * 8); L.kbm = take(((CLS * N + 63) / 64) * 8);
     L.xid = take(XCAP * 4);
@@ -298,8 +303,8 @@ struct Arena {   // the chain's arrays of one dataset in global memory (what exc
     PM2_DEV long long *nbs() const { return (long long *)(b + d->o_nbs); }              // NegBinom: sums [id][feature]
     PM2_DEV int *dl() const { return (int *)(b + d->o_dl); }
     PM2_DEV u8 *sstar() const { return (u8 *)(b + d->o_sstar); }
-    PM2_DEV double *lpx() const { return (double *)(b + d->o_cdf); }                      // log-predictives of the uncached clusters beyond XCAP
-    PM2_DEV int *xidx() const { return (int *)(b + d->o_cdf) + 2 * CLS * 64; }           // ... and their ids (CLS * N <= CLS * 64 entries each)
+    PM2_DEV double *lpx() const { return (double *)(b + d->o_s2x); }                      // log-predictives of the uncached clusters beyond XCAP
+    PM2_DEV int *xidx() const { return (int *)(b + d->o_s2x) + 2 * CLSMAX * 64; }        // ... and their ids (at most CLSMAX * N <= CLSMAX * 64 entries each)
 };
 
 struct DV {      // view of one dataset: LDS block + arena
@@ -387,8 +392,8 @@ struct Sweep2 {
     RegArr<double, PPL> lw;
     static constexpr int NCP = (PPL + 1) / 2;
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
-    u64 cslp;                   // class slot of the lane's particles per dataset, CSB bits each: bit offset CSB * (k * PPL + u)
-    static_assert(CSB * K * PPL <= 64 && (1 << CSB) >= CLS, "class slots of a lane's particles must fit one 64-bit word");
+    RegArr<u64, K> cslp;        // class slot of the lane's particles, one word per dataset, CSB bits each: bit offset CSB * u
+    static_assert(CSB * PPL <= 64 && (1 << CSB) >= CLSMAX, "class slots of a lane's particles of one dataset must fit one 64-bit word");
     RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
 #ifdef PM2_DETAIL_TIMERS
     long long phd_last;
@@ -405,6 +410,7 @@ struct Sweep2 {
     long long n, n1;
 
 #define L (ap->s2)
+#define CLS (ap->s2.cls)        // particle classes per dataset this handle's LDS tables hold (<= CLSMAX)
     // the packed registers are only ever indexed by compile-time constants: a run-time dataset index goes through these selects
     PM2_DEV void col_get(int k, int (&ck)[PPL]) const
     {
@@ -438,8 +444,8 @@ struct Sweep2 {
     {
         lw.set(u, x);
     }
-    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp >> (CSB * (k * PPL + u))) & (u64)((1 << CSB) - 1)); }
-    PM2_DEV void csl_put(int k, int u, int r) { const int sh = CSB * (k * PPL + u); cslp = (cslp & ~((u64)((1 << CSB) - 1) << sh)) | ((u64)r << sh); }
+    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp[k] >> (CSB * u)) & (u64)((1 << CSB) - 1)); }
+    PM2_DEV void csl_put(int k, int u, int r) { const int sh = CSB * u; cslp.set(k, (cslp[k] & ~((u64)((1 << CSB) - 1) << sh)) | ((u64)r << sh)); }
     PM2_DEV DV view(int k) const
     {
         DV v;
@@ -700,7 +706,7 @@ struct Sweep2 {
             int nf = 0;
             for (int q = 0; q < D; ++q) nf += fl[q];
             dsc[DS_NFLAG] = nf; dsc[DS_MAXID] = nu + 1; dsc[DS_NCLS] = 1; dsc[DS_NCOL] = 1; dsc[DS_NDX] = 0; dsc[DS_NX] = 0;
-            dsc[DS_DIRTY] = 1; dsc[DS_CHANGED] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_NEEDMASK] = 0; dsc[DS_NCLONE] = 0; dsc[DS_ND] = 0; dsc[DS_NDLOW] = 0;
+            dsc[DS_DIRTY] = 1; dsc[DS_CHANGED] = 0; dsc[DS_FOLLOW] = 0; dsc[DS_NEEDMASK] = 0; dsc[DS_NCLONE] = 0; dsc[DS_ND] = 0; dsc[DS_NDLOW] = 0; dsc[DS_HALT] = 0;
             lds<int>(v.base + L.clsval)[0] = 1; lds<int>(v.base + L.clslead)[0] = 0; lds<int>(v.base + L.leadcol)[0] = 0;
         }
         PM2_WAVE_BARRIER();
@@ -964,12 +970,17 @@ struct Sweep2 {
             nd += ndx;
             for (int w = 0; w < (CLS * N + 63) / 64; ++w) {
                 const u64 bits = kbm[w];
-                if ((bits >> lane) & 1ull) klist[nk + pm2_popc64(bits & below)] = (u16)(w * 64 + lane);
+                const int at = nk + pm2_popc64(bits & below);
+                if (((bits >> lane) & 1ull) && at < L.kcap) klist[at] = (u16)(w * 64 + lane);
                 nk += pm2_popc64(bits);
             }
             PM2_WAVE_BARRIER();
             for (int w = lane; w < (v.idcap + 63) / 64; w += 64) cbm[w] = 0;
             for (int w = lane; w < (CLS * N + 63) / 64; w += 64) kbm[w] = 0;
+        }
+        if (nk > L.kcap) {                  // more touched (class, label) keys than the lists hold: as good as too many classes
+            if (lane == 0) { sc()[SC_FAIL] = 4; sc()[SC_TMP1] = nk; dsc[DS_HALT] = 1; dsc[DS_ND] = 0; dsc[DS_FOLLOW] = 0; }
+            return false;
         }
         auto chosen = [&](int e) -> int { if (e < nd_low) return (int)clist[e]; return PM2_G(const int, v.ar.dl())[e - nd_low]; };
         unsigned *minp = lds<unsigned>(v.base + L.minp);
@@ -1007,6 +1018,9 @@ struct Sweep2 {
                 return true;
             }
         }
+        // Nothing below changes the chain's state before the step is known to fit this kernel's tables (pool capacity, 16-bit ids,
+        // CLS particle classes): a dataset whose step does not fit stops here with its state as the observation found it, and the
+        // general kernel carries the chain on from this observation (hand_over).
         // -- C1: clone or in place (:286-299): a chosen cluster all of whose references were chosen is updated in place
         PHC(2);
         for (int e0 = 0; e0 < nd; e0 += 64) {
@@ -1019,22 +1033,9 @@ struct Sweep2 {
         PM2_WAVE_BARRIER();
         int nclone = 0;
         for (int w = 0; w < P / 64; ++w) nclone += pm2_popc64(bmc[w]);
-        if (maxid + nclone > ap->cap) { if (lane == 0) sc()[SC_FAIL] = 1; return false; }      // PMDI_E_POOL
-        if (maxid + nclone > 0xFFFF) { if (lane == 0) sc()[SC_FAIL] = 3; return false; }       // (ids travel as 16-bit values in the LDS tables: the general kernel's chain)
-        for (int e0 = 0; e0 < nd; e0 += 64) {
-            const int e = e0 + lane;
-            if (e < nd) {
-                const int c = chosen(e);
-                const int ncp = v.ncop_get(c), fp = v.firstp_get(c);
-                const int cnt_c = v.counts_get(c);
-                const bool needs = ncp != cnt_c;
-                const int t = needs ? maxid + 1 + popc_below64(bmc, fp) : c;       // first-appearance order over the particles (:290-292)
-                v.tgt_set(c, t);
-                const int nnew = v.cn_get(c) + 1;
-                if (needs) { v.counts_set(c, cnt_c - ncp); v.counts_set(t, ncp); }         // (:293-294)
-                v.cn_set(t, nnew);
-            }
-        }
+        if (maxid + nclone > ap->cap) { if (lane == 0) { sc()[SC_FAIL] = 1; sc()[SC_TMP2] = 1; } return false; }      // PMDI_E_POOL
+        // (ids travel as 16-bit values in the LDS tables: beyond that the chain is the general kernel's)
+        if (maxid + nclone > 0xFFFF) { if (lane == 0) { sc()[SC_FAIL] = 3; dsc[DS_HALT] = 1; dsc[DS_ND] = 0; dsc[DS_FOLLOW] = 0; } return false; }
         // -- C2: class ids of the next step (:266-272): a (class, label) key met for the first time in this Gibbs iteration gets
         // the next id in particle order (curr_id restarts at 0 every step: Q1), others reuse the id stored under the key
         PHC(3);
@@ -1053,12 +1054,8 @@ struct Sweep2 {
                 const int key = klist[j];
                 const int r = key / N, ns = key - r * N;
                 int v0 = (ap->q1 == 1) ? 0 : (int)lds<u16>(v.base + L.nidv)[key];
-                if (v0 <= 0) {
-                    v0 = 1 + popc_below64(bmf, (int)(minp[key] >> 16));            // curr_id += 1 (:267-269)
-                    if (ap->q1 == 0) PM2_G(int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + ns] = v0;
-                    dsc[DS_CHANGED] = 1;                                            // (new_id changed under a key of this class)
-                }
-                if (v0 != lds<int>(v.base + L.clsval)[r]) dsc[DS_CHANGED] = 1;       // (the class does not map to itself)
+                if (v0 <= 0) v0 = 1 + popc_below64(bmf, (int)(minp[key] >> 16));     // curr_id += 1 (:267-269); stored below, once the step is known to fit
+                (void)r; (void)ns;
                 kval[j] = (u16)v0;
             }
         }
@@ -1092,7 +1089,41 @@ struct Sweep2 {
             }
             nrep += pm2_popc64(PM2_BALLOT(rep));
         }
-        if (nrep > CLS) { if (lane == 0) { sc()[SC_FAIL] = 4; sc()[SC_TMP1] = nrep; } return false; }           // too many particle classes
+        if (nrep > CLS) {                                                                                        // too many particle classes
+            if (lane == 0) { sc()[SC_FAIL] = 4; sc()[SC_TMP1] = nrep; dsc[DS_HALT] = 1; dsc[DS_ND] = 0; dsc[DS_FOLLOW] = 0; }
+            return false;
+        }
+        PM2_WAVE_BARRIER();
+        // -- the step fits: from here on the tables change.  Targets, reference counts and sizes of the chosen clusters (:290-294) ...
+        for (int e0 = 0; e0 < nd; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < nd) {
+                const int c = chosen(e);
+                const int ncp = v.ncop_get(c), fp = v.firstp_get(c);
+                const int cnt_c = v.counts_get(c);
+                const bool needs = ncp != cnt_c;
+                const int t = needs ? maxid + 1 + popc_below64(bmc, fp) : c;       // first-appearance order over the particles (:290-292)
+                v.tgt_set(c, t);
+                const int nnew = v.cn_get(c) + 1;
+                if (needs) { v.counts_set(c, cnt_c - ncp); v.counts_set(t, ncp); }         // (:293-294)
+                v.cn_set(t, nnew);
+            }
+        }
+        // ... and new_id under the keys met for the first time (:267-269)
+        for (int j0 = 0; j0 < nk; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < nk) {
+                const int key = klist[j];
+                const int r = key / N, ns = key - r * N;
+                const int v_old = (ap->q1 == 1) ? 0 : (int)lds<u16>(v.base + L.nidv)[key];
+                const int v0 = kval[j];
+                if (v_old <= 0) {
+                    if (ap->q1 == 0) PM2_G(int, v.ar.newid())[(size_t)(lds<int>(v.base + L.clsval)[r] - 1) * N + ns] = v0;
+                    dsc[DS_CHANGED] = 1;                                            // (new_id changed under a key of this class)
+                }
+                if (v0 != lds<int>(v.base + L.clsval)[r]) dsc[DS_CHANGED] = 1;       // (the class does not map to itself)
+            }
+        }
         PM2_WAVE_BARRIER();
         // -- C3: column splits (:301-308): particles of one column that chose the same label move together; the group whose chosen
         // cluster was cloned takes a copy of the column with that entry replaced -- or the column itself when nobody stays behind
@@ -1595,7 +1626,7 @@ struct Sweep2 {
             for (int uu = 0; uu < PPL; ++uu) { const int p = tid * PPL + uu; scol[p] = (u16)ck[uu]; scsl[p] = (u8)rk[uu]; }
             for (int e = tid; e < ncol_old; e += T) mult[e] = 0;
             for (int e = tid; e <= oldmax && e < v.idcap; e += T) hist[e] = 0;
-            if (tid < CLS) lds<int>(L.red)[RI_CLSMIN + tid] = 0x7fffffff;
+            if (tid < CLSMAX) lds<int>(L.red)[RI_CLSMIN + tid] = 0x7fffffff;
             if (tid == 0) sc()[SC_TMP0] = 0;                 // ids moved by this dataset's renumbering (counted below, barriers away)
             PM2_BARRIER();
             // particle[:, partstar, k], particle_id[partstar, k] (:322-323): a particle takes its ancestor's column index and class
@@ -1623,7 +1654,7 @@ struct Sweep2 {
                 const u64 act = PM2_BALLOT(start);
                 if (act) {
                     const int l0 = pm2_ffs64(act) - 1;
-                    const int key = cl * CLS + r;
+                    const int key = cl * CLSMAX + r;
                     const int key0 = readlane_i(key, l0);             // (every lane reads it: a cross-lane read must not sit behind `start &&`)
                     const bool uni = PM2_BALLOT(start && key == key0) == act;
                     int tot = cnt;
@@ -1859,7 +1890,8 @@ struct Sweep2 {
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int j = 0; j < NCP; ++j) colp.set(k * NCP + j, 0u);
-        cslp = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) cslp.set(k, 0ull);
 #pragma unroll
         for (int s = 0; s < NS; ++s) { c_mu.set(s, 0.0); c_lam.set(s, 1.0); }
         PM2_BARRIER();
@@ -2038,7 +2070,11 @@ struct Sweep2 {
             PM2_BARRIER();
             PHC(15);
             PH2(7);
-            if (sc()[SC_FAIL]) { failed = sc()[SC_FAIL]; break; }
+            int fcode = sc()[SC_FAIL];
+            if (fcode && sc()[SC_TMP2]) fcode = 1;                              // (the pool ran out in some dataset: an error whatever the others say)
+            if (fcode && (fcode == 1 || !a.resume)) { failed = fcode; break; }
+            // (fcode != 0 from here on: a dataset's step does not fit this kernel's tables and that dataset has changed nothing; the
+            // datasets whose step did fit finish it below, then the chain is handed to the general kernel at this observation)
             // ---- statistics of the chosen clusters the owner waves left to everybody
             if (help_stats(i_cur)) PM2_BARRIER();
             // ---- every particle follows its group: new column, new class slot
@@ -2063,6 +2099,7 @@ struct Sweep2 {
                 }
                 col_put(k, ck);
             }
+            if (fcode) { hand_over(pos, fcode, t_start); return; }
             double ess = (double)P;
             if (!lw_flat) {
                 double sa = 0.0, sq = 0.0;
@@ -2136,6 +2173,85 @@ struct Sweep2 {
 #undef PH2
     }
 
+    // ---- the tables of dataset k as the arena holds them for everybody else (pmdi_export_state, the general kernel): the columns, the
+    //      column and class of every particle, reference counts, cluster sizes -------------------------------------------------------
+    PM2_DEV void export_dataset(int k)
+    {
+        const auto &a = *ap;
+        const DV v = view(k);
+        const int ncol = v.dsc()[DS_NCOL], maxid = v.dsc()[DS_MAXID];
+        auto tg = PM2_G(int, v.ar.tabg());
+        for (int e = tid; e < ncol * N && e < v.cols_l * N; e += T) tg[e] = (int)lds<u16>(v.base + L.tab)[e];
+        auto cg = PM2_G(int, v.ar.colg());
+        auto pg = PM2_G(int, v.ar.pidg());
+        int ck[PPL];
+        col_get(k, ck);
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) { cg[tid * PPL + u] = ck[u]; pg[tid * PPL + u] = lds<int>(v.base + L.clsval)[csl_get(k, u)]; }
+        auto cng = PM2_G(int, v.ar.cn());
+        auto ctg = PM2_G(int, v.ar.counts());
+        for (int id = tid; id < v.idcap && id <= a.cap; id += T) { cng[id] = (id <= maxid) ? lds<int>(v.base + L.cn)[id] : cng[id]; ctg[id] = (id <= maxid) ? lds<int>(v.base + L.counts)[id] : 0; }
+        for (int id = maxid + 1 + tid; id <= a.cap; id += T) ctg[id] = 0;
+        if (tid == 0) {
+            PM2_G(int, a.kstate)[((size_t)chain * PMDI_KMAX_I + k) * 2] = maxid;
+            PM2_G(int, a.kstate)[((size_t)chain * PMDI_KMAX_I + k) * 2 + 1] = 0;
+        }
+    }
+
+    // ---- a step of observation `pos` does not fit this kernel's tables in some dataset (more than CLS particle classes, or cluster ids
+    //      beyond 16 bits): the chain goes to the general kernel HERE, not back to the start of the sweep.  The datasets that halted
+    //      have changed nothing (phase_c checks before it commits); the others have finished the step.  Everything the general kernel
+    //      keeps between steps is written where it looks for it: tables and per-particle columns / classes (export_dataset), the
+    //      step scratch of the per-id tables back to idle, log-weights (they hold this observation's increments and the Phi term: the
+    //      draws of ALL datasets are done and recorded in the history), counters, and the resume record: position, which datasets are
+    //      done, live columns per dataset.  pmdi_sweep.hip replays the bookkeeping of the halted datasets from the recorded draws and
+    //      carries on with calc_ESS of this observation.
+    PM2_DEV void hand_over(long long pos, int fcode, long long t_start)
+    {
+        const auto &a = *ap;
+        PM2_BARRIER();
+        int done_mask = 0;
+#pragma nounroll
+        for (int k = 0; k < K; ++k) {
+            const DV v = view(k);
+            int *dsc = v.dsc();
+            const bool halted = dsc[DS_HALT] != 0;
+            if (!halted) done_mask |= 1 << k;
+            export_dataset(k);
+            auto g1 = PM2_G(int, v.ar.ncop());
+            auto g2 = PM2_G(int, v.ar.firstp());
+            for (int e = tid; e < v.idcap && e <= a.cap; e += T) { g1[e] = 0; g2[e] = 0x7fffffff; }
+            if (halted) {                 // what its census marked beyond the LDS tables
+                const int ndx = dsc[DS_NDX];
+                for (int e = tid; e < ndx; e += T) { const int id = PM2_G(const int, v.ar.dl())[e]; g1[id] = 0; g2[id] = 0x7fffffff; }
+            }
+            if (tid == 0) {
+                PM2_G(int, a.resume)[(size_t)chain * 16 + 2 + k] = dsc[DS_NCOL];
+                if (halted) wk(k)[WK_EVAL] += dsc[DS_NNEED];          // (its clusters were evaluated; the replay will not do that again)
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PPL; ++u) PM2_G(double, a.uscratch)[(size_t)chain * K * P + tid * PPL + u] = lw[u];
+        PM2_BARRIER();
+        if (tid == 0) {
+            auto st = PM2_G(long long, a.stats) + (size_t)chain * 8;
+            const long long *s = stat();
+            st[ST_NOPS] = s[0]; st[ST_NRESAMPLE] = s[1]; st[ST_NCLONES] = s[2]; st[ST_MAXID] = s[3]; st[ST_SUMCLASSES] = s[4];
+            st[5] = s[5]; st[6] = 0; st[7] = 0;
+            PM2_G(int, a.resume)[(size_t)chain * 16] = (int)pos;
+            PM2_G(int, a.resume)[(size_t)chain * 16 + 1] = done_mask;
+            PM2_G(int, a.requeue)[chain] = 1;
+            if (!a.err_keep) PM2_G(int, a.err)[chain] = 0;
+            if (a.handed) PM2_G(int, a.handed)[chain] = a.sweep_no;
+            if (a.requeue_total) {
+                pm2_atomic_add((u64 *)a.requeue_total + 3, (u64)1); pm2_atomic_add((u64 *)a.requeue_total + (fcode - 2), (u64)1);
+                if (fcode == 4 && sc()[SC_TMP1] > 2 * CLS) pm2_atomic_add((u64 *)a.requeue_total + 1, (u64)1);
+            }
+            PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
+        }
+        if (a.work && tid < K * 8) PM2_G(long long, a.work)[((size_t)chain * PMDI_KMAX_I) * 8 + tid] = lds<long long>(L.wk)[tid];
+    }
+
     // ---- particle pick (src/pmdi.jl:345-350), s = sstar[p_star, :, :] (:373), counters, the state the debug export reads --------------
     PM2_DEV void finish(long long t_start)
     {
@@ -2182,26 +2298,7 @@ struct Sweep2 {
             for (int u = 0; u < PPL; ++u) PM2_G(double, a.lw_out)[(size_t)chain * P + tid * PPL + u] = lw[u];
         // what pmdi_export_state reads: the columns, the column and class of every particle, counts, cluster sizes
 #pragma nounroll
-        for (int k = 0; k < K; ++k) {
-            const DV v = view(k);
-            const int ncol = v.dsc()[DS_NCOL], maxid = v.dsc()[DS_MAXID];
-            auto tg = PM2_G(int, v.ar.tabg());
-            for (int e = tid; e < ncol * N && e < v.cols_l * N; e += T) tg[e] = (int)lds<u16>(v.base + L.tab)[e];
-            auto cg = PM2_G(int, v.ar.colg());
-            auto pg = PM2_G(int, v.ar.pidg());
-            int ck[PPL];
-            col_get(k, ck);
-#pragma unroll
-            for (int u = 0; u < PPL; ++u) { cg[tid * PPL + u] = ck[u]; pg[tid * PPL + u] = lds<int>(v.base + L.clsval)[csl_get(k, u)]; }
-            auto cng = PM2_G(int, v.ar.cn());
-            auto ctg = PM2_G(int, v.ar.counts());
-            for (int id = tid; id < v.idcap && id <= a.cap; id += T) { cng[id] = (id <= maxid) ? lds<int>(v.base + L.cn)[id] : cng[id]; ctg[id] = (id <= maxid) ? lds<int>(v.base + L.counts)[id] : 0; }
-            for (int id = maxid + 1 + tid; id <= a.cap; id += T) ctg[id] = 0;
-            if (tid == 0) {
-                PM2_G(int, a.kstate)[((size_t)chain * PMDI_KMAX_I + k) * 2] = maxid;
-                PM2_G(int, a.kstate)[((size_t)chain * PMDI_KMAX_I + k) * 2 + 1] = 0;
-            }
-        }
+        for (int k = 0; k < K; ++k) export_dataset(k);
         if (tid == 0) {
             auto st = PM2_G(long long, a.stats) + (size_t)chain * 8;
             const long long *s = stat();
@@ -2210,10 +2307,12 @@ struct Sweep2 {
             st[5] = s[5]; st[6] = 0; st[7] = 0;
             if (!a.err_keep) PM2_G(int, a.err)[chain] = 0;
             if (a.requeue) PM2_G(int, a.requeue)[chain] = 0;
+            if (a.swept_by) PM2_G(int, a.swept_by)[chain] = 1;
             PM2_G(long long, a.cost)[chain] = PM2_CLOCK() - t_start;
         }
         if (a.work && tid < K * 8) PM2_G(long long, a.work)[((size_t)chain * PMDI_KMAX_I) * 8 + tid] = lds<long long>(L.wk)[tid];
     }
+#undef CLS
 #undef L
 };
 

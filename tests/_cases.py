@@ -51,6 +51,23 @@ def t5_invariants(state, N, P, K, n_obs):
         assert (cnt == state["counts"][k][:cap]).all()                    # :149-153,:158-162
 
 
+def check_work_counters(wk, rec, trace, N, kernel):
+    """The device's work counters of one chain-sweep (wk: (K, 8)) against the oracle's per-step record.  Clusters evaluated
+    (column 0) depends on which kernel swept the chain (pmdi_chain_swept_by): the settled-chain kernel (1) evaluates the reachable
+    clusters in every step; the general kernel (0) every live id in a step whose (class, label) items outgrow its LDS tables; a
+    chain handed over mid-sweep (2) lies between the two.  Columns met by resampling events and copy-on-write splits are the same
+    everywhere."""
+    ev_need, cols, splits = expected_work_counters(rec, trace, N, item_cap=None)
+    ev_gen, _, _ = expected_work_counters(rec, trace, N)
+    if kernel == 1:
+        assert (wk[:, 0] == ev_need).all(), (wk[:, 0], ev_need)
+    elif kernel == 0:
+        assert (wk[:, 0] == ev_gen).all(), (wk[:, 0], ev_gen)
+    else:
+        assert (wk[:, 0] >= ev_need).all() and (wk[:, 0] <= ev_gen).all(), (wk[:, 0], ev_need, ev_gen)
+    assert (wk[:, 5] == cols).all() and (wk[:, 6] == splits).all(), (wk, cols, splits)
+
+
 def expected_work_counters(rec, trace, N, item_cap="auto"):
     """What the device's work counters [WK_EVAL, WK_COLS, WK_SPLITS] must equal, per dataset, from the oracle's per-step record
     (pmdi_oracle_debug_steps) and trace of the same sweep.  Clusters evaluated: the clusters the class leaders read at

@@ -23,7 +23,7 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
     d.o_particle[0] = take((size_t)N * P * 4);
     d.o_particle[1] = take((size_t)N * P * 4);
     d.o_col = take((size_t)P * 4);
-    d.o_cgrp = take((size_t)N * P * 8);
+    d.o_cgrp = take((size_t)(N > 3 ? N : 3) * P * 8);
     d.o_pid = take((size_t)P * 4);
     d.o_sid = take((size_t)P * 4);
     d.o_kv = take((size_t)P * 4);
@@ -37,6 +37,7 @@ size_t layout_arena(DsetDev &d, int N, int P, long long cap, long long n_rows_ss
     d.o_clsval = take((size_t)P * 4);
     d.o_cdf = take((size_t)P * (N + 2) * 8);
     d.o_dl = take((size_t)3 * P * 4);
+    d.o_s2x = take((size_t)2048 * 12);
     d.o_cn = take(ids * 4);
     if (d.kind == K_GAUSSIAN) d.o_sb = take(ids * d.D * 16);
     else if (d.kind == K_CATEGORICAL) d.o_cnt = take(ids * d.D * d.L * 4);
@@ -54,7 +55,7 @@ struct Emu {
     std::vector<std::vector<char>> arena;
     DsetDev ds[PMDI_KMAX_I];
     int Dmax = 0, sumD = 0;
-    int cols_l, idcap;
+    int cols_l, idcap, cls;
 };
 
 struct RunArg { const SweepArgs *a; int K, PPL, NW; };
@@ -84,12 +85,12 @@ extern "C" {
 
 // data[k]: n x D_k row-major doubles (integer types: levels 1..L / counts >= 0 as doubles); kinds[k]: K_GAUSSIAN / K_CATEGORICAL / K_NEGBINOM
 void *emu_create(int K, long long n, int N, int P, const int *D, const double *const *data, unsigned long long seed, int q1,
-                 int cols_l, int idcap, const int *kinds)
+                 int cols_l, int idcap, const int *kinds, int cls)
 {
     if (K < 1 || K > pmdi_s2::KMAX2 || (P != 256 && P != 512 && P != 1024 && P != 2048) || N > 64) return nullptr;
     Emu *e = new Emu();
     e->K = K; e->N = N; e->P = P; e->n = n; e->cap = (long long)N * P + 1; e->seed = seed; e->q1 = q1;
-    e->cols_l = cols_l; e->idcap = idcap;
+    e->cols_l = cols_l; e->idcap = idcap; e->cls = cls;
     memset(e->ds, 0, sizeof(e->ds));
     e->x.resize(K); e->gtab.resize(K); e->arena.resize(K); e->lhtab.resize(K); e->lgtab.resize(K); e->xi.resize(K); e->maxcol.resize(K);
     int flag_off = 0;
@@ -153,7 +154,7 @@ long long emu_lds_bytes(void *h)
 {
     Emu *e = (Emu *)h;
     S2Layout L;
-    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, L);
+    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, e->cls, L);
     return L.total;
 }
 
@@ -177,7 +178,7 @@ int emu_sweep(void *h, long long iter, const int *s_in, const int *order, long l
     std::vector<int> kstate(PMDI_KMAX_I * 2, 0);
     std::vector<long long> wk(PMDI_KMAX_I * 8, 0);
     a.err = &err; a.cost = &cost; a.kstate = kstate.data(); a.work = wk.data();
-    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, a.s2);
+    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, e->cls, a.s2);
     const int nw = e->P > 1024 ? 8 : 4;
     RunArg r{&a, e->K, e->P / (64 * nw), nw};
     wavesim::run_block(64 * nw, 0, (size_t)a.s2.total, entry, &r);

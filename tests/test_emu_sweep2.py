@@ -35,12 +35,12 @@ def _mixed(rng, n, kinds, sep=3.0):
     return data, z
 
 
-def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0, variant="", kinds=None):
+def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0, variant="", kinds=None, cls=16):
     from _emu import EmuSweeper
     rng = np.random.default_rng(seed)
     n, K = data[0].shape[0], len(data)
     kinds = kinds or ["gaussian"] * K
-    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant, kinds=kinds)
+    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant, kinds=kinds, cls=cls)
     o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1)
     rec = o.debug_steps(n - n1 + 1)
     requeued = []
@@ -162,6 +162,18 @@ def test_mixed_cluster_types_with_feature_flags_and_arena_tables(O):
     data, z = _mixed(rng, 160, kinds)
     fl = [(rng.random(d.shape[1]) < 0.7).astype(np.uint8) for d in data]
     _compare(O, data, 6, 512, 2, 77, 40, settle=True, truth=z, flags=fl, allow_requeue=1, kinds=kinds, cols_l=2, idcap=8, scramble=0.2)
+
+
+def test_up_to_32_particle_classes_per_dataset(O):
+    """The class slots of a lane are 5 bits wide; how many classes the LDS tables hold is a layout parameter (16 .. 32, the host's
+    choice for the LDS budget).  A planted start whose steps fan one class out into 17 .. 32: handed back with 16, swept in place
+    with 32 -- same results as the oracle, whose class count per step is checked to be in that range."""
+    rng = np.random.default_rng(24)
+    data, z = _mixed(rng, 150, ["gaussian", "categorical"])
+    with pytest.raises(AssertionError, match="reason 4"):
+        _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=16)
+    rec = _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=32)
+    assert 16 < rec[:, :, 0].max() <= 32, rec[:, :, 0].max()
 
 
 def test_eight_wave_workgroup_for_2048_particles(O):

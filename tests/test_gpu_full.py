@@ -164,7 +164,7 @@ def _one_iteration_vs_oracle(pkg, O, w, sw, g, chains, it, base_seed, fsel, tag)
     """ONE whole Gibbs iteration of the device-resident chains `chains`, compared piece by piece with the oracle from the same
     state: hyper-parameter kernel, sweep (allocations, p_star, counters, work counters, log-weights, exported state, T5
     invariants), feature selection, label alignment."""
-    from _cases import expected_work_counters
+    from _cases import check_work_counters
     n, K, N, P = w["n"], w["K"], w["N"], w["P"]
     n1 = g.n1
     st0 = {c: g.get(c) for c in chains}
@@ -187,6 +187,7 @@ def _one_iteration_vs_oracle(pkg, O, w, sw, g, chains, it, base_seed, fsel, tag)
     g.step(pkg.STEP_SWEEP)
     res = g.results()
     work = sw.work_counters()
+    swept = sw.swept_by()             # which kernel finished each chain's sweep: 0 general, 1 settled-chain, 2 general after a hand-over
     oracles = {}
     for c in chains:
         # ---- the sweep at full size: same inputs on both sides (the device's post-update hyper-parameters)
@@ -197,7 +198,7 @@ def _one_iteration_vs_oracle(pkg, O, w, sw, g, chains, it, base_seed, fsel, tag)
         flags = [b["flags"][sum(w["D"][:k]):sum(w["D"][:k + 1])] for k in range(K)]
         ro = orc.sweep(it, b["s"], b["order"], n1, Pi, b["Phi"], flags, lw_init=1.0, trace=True)
         st2 = g.get(c)
-        print(f"{tag}: chain {c}, oracle sweep {ro['stats']['seconds']:.1f} s, stats {ro['stats']}")
+        print(f"{tag}: chain {c} swept by kernel {int(swept[c])} (0 general, 1 settled-chain, 2 handed over mid-sweep), oracle sweep {ro['stats']['seconds']:.1f} s, stats {ro['stats']}")
         if not (st2["s"] == ro["s"]).all():
             # where did the chain leave the oracle?  (shuffled position of the first differing allocation, per dataset)
             pos_of = np.empty(n, dtype=np.int64); pos_of[b["order"] - 1] = np.arange(n)
@@ -210,9 +211,8 @@ def _one_iteration_vs_oracle(pkg, O, w, sw, g, chains, it, base_seed, fsel, tag)
         assert np.allclose(res["logweight"][c], ro["logweight"], rtol=1e-6, atol=1e-6)       # north_star tolerance
         wk = work[c]
         up, mv = orc.work()
-        ev, cols, splits = expected_work_counters(rec, ro["trace"], N)
         assert (wk[:, 1] == up).all() and (wk[:, 3] == mv).all() and wk[:, 2].sum() == ro["stats"]["n_clones"]
-        assert (wk[:, 0] == ev).all() and (wk[:, 5] == cols).all() and (wk[:, 6] == splits).all(), (wk, ev, cols, splits)
+        check_work_counters(wk, rec, ro["trace"], N, int(swept[c]))
         dev_state, ora_state = sw.export_state(c), orc.export()
         t5_invariants(dev_state, N, P, K, n)
         assert (dev_state["particle"] == ora_state["particle"]).all()
@@ -237,10 +237,11 @@ def _one_iteration_vs_oracle(pkg, O, w, sw, g, chains, it, base_seed, fsel, tag)
         st3 = g.get(c)
         assert (st3["s"] == np.array(hy.s)).all() and (st3["gamma"] == hy.gamma).all()
         oracles[c][0].close(); hy.close()
-    return {c: oracles[c][1] for c in chains}
+    return {c: dict(oracles[c][1], kernel=int(swept[c])) for c in chains}
 
 
-@pytest.mark.parametrize("cfg,ksplit", [("cfg3", 0), ("cfg3", 1), ("HL", 0), ("HL", 1), ("cfg4", 0), ("cfg4", 1), ("cfg5", None)])
+@pytest.mark.parametrize("cfg,ksplit", [("cfg3", 0), ("cfg3", 1), ("HL", 0), ("HL", 1), ("cfg4", 0), ("cfg4", 1), ("cfg5", None),
+                                        ("HL", "settled"), ("cfg3", "settled"), ("cfg4", "settled")])
 def test_full_size_mid_chain_iteration_vs_oracle(pkg, O, cfg, ksplit, monkeypatch):
     """BASELINE.json's configs at their FULL sizes (n, K, D, N, P as stated; cfg4: P = 2 048, N = 50; cfg5: P = 4 096,
     N = 50, D = 200, feature selection on): a chain is burnt in on the device, then ONE whole iteration is compared
@@ -251,6 +252,14 @@ def test_full_size_mid_chain_iteration_vs_oracle(pkg, O, cfg, ksplit, monkeypatc
     w = workloads.make(cfg)
     n, K, N, P = w["n"], w["K"], w["N"], w["P"]
     assert (n, N, P) == SIZES[cfg]
+    forced = ksplit == "settled"
+    if forced:
+        # every chain starts every sweep on the settled-chain kernel (from the random start too: it hands the chain over to the general
+        # kernel at the first observation whose step does not fit -- the continuation is what the burn-in sweeps run on) and no chain
+        # is kept on the general kernel afterwards: the compared sweep is the settled-chain kernel's, whole or up to a hand-over
+        monkeypatch.setenv("PMDI_SETTLED", "2")
+        monkeypatch.setenv("PMDI_STICKY", "0")
+        ksplit = 0
     if ksplit is not None:
         monkeypatch.setenv("PMDI_KSPLIT", str(ksplit))
     fsel = cfg == "cfg5"
@@ -270,7 +279,10 @@ def test_full_size_mid_chain_iteration_vs_oracle(pkg, O, cfg, ksplit, monkeypatc
     # the chain whose last burn-in sweep resampled most (a chain can collapse into one cluster per dataset, where
     # every step is unanimous and nothing is resampled: not the state this test is after)
     c = int(np.argmax(g.results()["stats"][:, 1]))
-    ro = _one_iteration_vs_oracle(pkg, O, w, sw, g, [c], FULL[cfg] + 1, base_seed, fsel, f"{cfg}/ksplit={ksplit}")[c]
+    ro = _one_iteration_vs_oracle(pkg, O, w, sw, g, [c], FULL[cfg] + 1, base_seed, fsel, f"{cfg}/ksplit={ksplit}{'/settled' if forced else ''}")[c]
+    if forced:
+        assert sw.settled and ro["kernel"] in (1, 2), ro["kernel"]
+        assert sw.given_back()[3] >= 1        # (the burn-in from the random start went through the hand-over)
     assert ro["stats"]["n_resamples"] > 0 and ro["stats"]["n_operations"] > 2 * K * (n - g.n1 + 1)   # a genuinely mid-chain state
     g.close(); sw.close()
 

@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from _cases import expected_work_counters, golden_cases, load_golden, replay, t5_invariants
+from _cases import check_work_counters, expected_work_counters, golden_cases, load_golden, replay, t5_invariants
 from conftest import make_mixed, random_hypers
 
 pytestmark = pytest.mark.gpu
@@ -60,9 +60,7 @@ def _compare_run(pkg, O, data, kinds, N, P, iters, seed, n1, q1=0, flags=None, b
         assert (wk[:, 1] == up).all() and (wk[:, 3] == mv).all() and wk[:, 2].sum() == ro["stats"]["n_clones"]
         # ... and, pinned to the oracle's per-step record: clusters evaluated (the ones a class leader reads at src/pmdi.jl:232),
         # distinct columns of particle[:, :, k] met by the resampling events, columns made by copy-on-write splits
-        ev, cols, splits = expected_work_counters(rec, ro["trace"], N)
-        assert (wk[:, 0] == ev).all(), (wk[:, 0], ev)
-        assert (wk[:, 5] == cols).all() and (wk[:, 6] == splits).all(), (wk[:, 5:7], cols, splits)
+        check_work_counters(wk, rec, ro["trace"], N, int(g.sw.swept_by()[0]))
         s = ro["s"]
     if check_state:
         eg, eo = g.sw.export_state(0), o.export()
@@ -350,6 +348,7 @@ def test_settled_chain_kernel_equals_oracle(pkg, O, monkeypatch, K, P, n, N):
             h[0][:3] += 1.0; h[0][:] = h[0] / h[0].sum(0)
         rg = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]), trace=True)
         wk = sw.work_counters()
+        kern = sw.swept_by()
         for c in range(C):
             ro = orcs[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1], trace=True)
             bad = np.where(~np.isclose(rg["trace"][c], ro["trace"], rtol=1e-9, atol=1e-9).all(axis=1))[0]
@@ -359,9 +358,8 @@ def test_settled_chain_kernel_equals_oracle(pkg, O, monkeypatch, K, P, n, N):
             for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
                 assert rg["stats"][c][key] == ro["stats"][key], key
             up, mv = orcs[c].work()
-            ev, cols, splits = expected_work_counters(recs[c], ro["trace"], N)
-            assert (wk[c][:, 1] == up).all() and (wk[c][:, 3] == mv).all() and (wk[c][:, 0] == ev).all()
-            assert (wk[c][:, 5] == cols).all() and (wk[c][:, 6] == splits).all()
+            assert (wk[c][:, 1] == up).all() and (wk[c][:, 3] == mv).all()
+            check_work_counters(wk[c], recs[c], ro["trace"], N, int(kern[c]))
             eg, eo = sw.export_state(c), orcs[c].export()
             assert (eg["particle"] == eo["particle"]).all() and (eg["max_id"] == eo["max_id"]).all()
             t5_invariants(eg, N, P, K, n)
@@ -426,6 +424,7 @@ def test_settled_chain_kernel_mixed_types_equal_oracle(pkg, O, monkeypatch, kind
             h[0][:3] += settle; h[0][:] = h[0] / h[0].sum(0)
         rg = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]), trace=True)
         wk = sw.work_counters()
+        kern = sw.swept_by()
         for c in range(C):
             ro = orcs[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1], trace=True)
             bad = np.where(~np.isclose(rg["trace"][c], ro["trace"], rtol=1e-9, atol=1e-9).all(axis=1))[0]
@@ -437,9 +436,8 @@ def test_settled_chain_kernel_mixed_types_equal_oracle(pkg, O, monkeypatch, kind
             for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
                 assert rg["stats"][c][key] == ro["stats"][key], key
             up, mv = orcs[c].work()
-            ev, cols, splits = expected_work_counters(recs[c], ro["trace"], N)
-            assert (wk[c][:, 1] == up).all() and (wk[c][:, 3] == mv).all() and (wk[c][:, 0] == ev).all()
-            assert (wk[c][:, 5] == cols).all() and (wk[c][:, 6] == splits).all()
+            assert (wk[c][:, 1] == up).all() and (wk[c][:, 3] == mv).all()
+            check_work_counters(wk[c], recs[c], ro["trace"], N, int(kern[c]))
             eg, eo = sw.export_state(c), orcs[c].export()
             assert (eg["particle"] == eo["particle"]).all() and (eg["max_id"] == eo["max_id"]).all()
             t5_invariants(eg, N, P, K, n)
