@@ -1396,6 +1396,76 @@ __device__ PMDI_COLD_FINAL void sweep_final(const SweepArgs *__restrict__ ap)
     }
 }
 
+// The first observation of a chain the settled-chain kernel handed over: its labels are drawn and recorded (:265), the increments and
+// the Phi term are in the log-weights.  A dataset whose step that kernel finished is done (`done` mask); the others still need the
+// step's bookkeeping -- class ids (:266-272), copy-on-write (:275-310) -- which is what the fallback step does with draws it did
+// not make itself (`converted`).  Out of line: nothing of this may cost the step loop a register.
+template <int T, int WPS>
+__device__ __noinline__ void sweep_replay(const SweepArgs *__restrict__ ap, long long pos, int i, int done)
+{
+    PMDI_PREAMBLE;
+    long long ph_last = 0;
+    int ph_cur = 0;
+    for (int k = 0; k < K; ++k) {
+        if ((done >> k) & 1) continue;
+        const DsetDev &d = dsb[k];
+        const KS s = make_ks(d, chain);
+        const int D = d.D;
+        const int maxid = sh.kmaxid[k], ncls = sh.kncls[k];
+        const ClsList cl{sh.cl_lead + k * PMDI_CLS_LDS, sh.cl_val + k * PMDI_CLS_LDS, s.clslead, s.clsval, PMDI_CLS_LDS};
+        for (int q = tid; q < D; q += T) {
+            if (d.kind == K_GAUSSIAN) sh.xs[q] = glob(d.xf)[(size_t)i * D + q]; else ((int *)sh.xs)[q] = glob(d.xi)[(size_t)i * D + q];
+        }
+        for (int p = tid; p < P; p += T) sh.news[k * P + p] = s.sstar[(size_t)pos * P + p];
+        for (int r = tid; r < ncls; r += T) sh.slot_of[cl.val(r)] = r;
+        if (tid == 0) sh.misc[M_OVF] = 0;
+        __syncthreads();
+        sweep_slow<T, WPS>(ap, k, i, pos, false, true, maxid, ncls, ph_last, ph_cur);
+        if (sh.misc[M_FAIL]) return;
+        if (tid == 0) {
+            const int nclone_r = sh.misc[M_NCLONE];
+            sh.stat[7] += 1;
+            sh.stat[0] += maxid;                  // src/__pmdi.jl:187
+            sh.stat[4] += ncls;
+            sh.stat[2] += nclone_r;
+            if (maxid + nclone_r > sh.stat[3]) sh.stat[3] = maxid + nclone_r;
+            sh.kmaxid[k] = maxid + nclone_r; sh.kncls[k] = sh.misc[M_NCLS];
+            sh.wk[k * 8 + WK_UPD] += sh.misc[M_ND]; sh.wk[k * 8 + WK_CLONE] += nclone_r;
+        }
+        __syncthreads();
+    }
+    // calc_ESS (src/misc.jl:15-25) and the resampling decision (src/pmdi.jl:317) of this observation, as the step loop does them
+    double mx = -INFINITY;
+    for (int p = tid; p < P; p += T) { const double v = sh.lw[p]; mx = (v > mx) ? v : mx; }
+    mx = block_max<T>(mx, gen(sh.red));
+    double sa = 0.0, sb2 = 0.0;
+    for (int p = tid; p < P; p += T) { const double w = exp(sh.lw[p] - mx); sa += w; sb2 += w * w; }
+    block_sum2<T>(sa, sb2, gen(sh.red));
+    double ess = (sa * sa) / sb2;
+    if (fabs(ess - 0.5 * (double)P) <= 1e-9 * (double)P) {         // (the reference's order of additions when the comparison is that close)
+        __syncthreads();
+        if (tid == 0) {
+            double na = 0.0, nb = 0.0;
+            for (int p = 0; p < P; ++p) { const double w = exp(sh.lw[p] - mx); na += w; nb += w * w; }
+            sh.red[40] = (na * na) / nb;
+        }
+        __syncthreads();
+        ess = sh.red[40];
+    }
+    const bool resample = ess <= 0.5 * (double)P;
+    if (resample) {
+        if (tid == 0) sh.stat[1] += 1;
+        sweep_resample<T>(ap, pos, mx);
+    }
+    if (tid == 0) sh.misc[M_XAB] = resample ? 1 : 0;              // (every log-weight equal again: what the caller's lw_uniform means)
+    if (a.trace_on && tid == 0) {
+        double *tr = a.trace + ((size_t)chain * (n - n1 + 1) + (pos - (n1 - 1))) * (2 + 2 * Kf);
+        tr[0] = ess; tr[1] = resample ? 1.0 : 0.0;
+        for (int k = 0; k < K; ++k) { tr[2 + k] = (double)sh.kmaxid[k]; tr[2 + Kf + k] = (double)sh.kncls[k]; }
+    }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------
 // WPS = minimum waves per SIMD the register allocation must allow (2 co-resident chains per CU
 // at T = 512 need 4)
@@ -1451,23 +1521,26 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 
     // a chain the settled-chain kernel handed over carries on at the observation where that kernel stopped: the bookkeeping of the
     // datasets it left undone is replayed from the recorded draws, then calc_ESS of that observation and everything after it
-    const bool resuming = a.resume_mode != 0 && a.resume != nullptr;
     long long pos0 = n1 - 1;
-    int replay_done = 0;
-    bool replay = false;
-    if (resuming) {
+    int failed = 0;
+    bool lw_uniform = true;     // every particle holds the same log-weight (then ESS == P exactly)
+#ifndef PMDI_NO_RESUME       // (tests/test_build_budget.py measures the step loop's spills without these out-of-line cold functions: the compiler's figure folds callees in)
+    if (a.resume_mode != 0 && a.resume != nullptr) {
         __syncthreads();
         sweep_resume_load<T>(ap);
-        pos0 = a.resume[(size_t)chain * 16];
-        replay_done = a.resume[(size_t)chain * 16 + 1];
-        replay = true;
+        const long long posr = a.resume[(size_t)chain * 16];
+        sweep_replay<T, WPS>(ap, posr, order[posr], a.resume[(size_t)chain * 16 + 1]);      // the whole of that observation
+        if (sh.misc[M_FAIL]) failed = 1;
+        lw_uniform = sh.misc[M_XAB] != 0;
+        __syncthreads();
+        if (tid == 0) sh.misc[M_XAB] = 0;
+        pos0 = posr + 1;
     } else
+#endif
     sweep_prefix<T>(ap);
     // ---- the sweep: src/pmdi.jl:209-342 ----
     PH(1);
-    int failed = 0;
-    bool lw_uniform = !resuming;     // every particle holds the same log-weight (then ESS == P exactly)
-    int i_next = order[pos0];
+    int i_next = pos0 < n ? order[pos0] : 0;
     double nx = 0.0;          // register-staged observation row of the upcoming step
     int nxi = 0;
     int ns0_next = s_in[i_next];   // ... and the reference trajectory's label there (dataset 0)
@@ -1505,35 +1578,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
             const int items = ncls * N;
             const bool small = items <= a.item_cap;
             if (ncls != 1) lw_uniform = false;
-            if (replay) {
-                // the first observation of a handed-over chain: its labels are drawn and recorded (:265), the increments and the Phi term
-                // are in the log-weights.  A dataset whose step the settled-chain kernel finished is done; the others still need the
-                // step's bookkeeping -- class ids (:266-272), copy-on-write (:275-310) -- which is what the fallback step does with
-                // draws it did not make itself (`converted`)
-                if (!((replay_done >> k) & 1)) {
-                    for (int q = tid; q < D; q += T) {
-                        if (d.kind == K_GAUSSIAN) sh.xs[q] = glob(d.xf)[(size_t)i * D + q]; else ((int *)sh.xs)[q] = glob(d.xi)[(size_t)i * D + q];
-                    }
-                    for (int p = tid; p < P; p += T) sh.news[k * P + p] = s.sstar[(size_t)pos * P + p];
-                    for (int r = tid; r < ncls; r += T) sh.slot_of[cl.val(r)] = r;
-                    if (tid == 0) sh.misc[M_OVF] = 0;
-                    __syncthreads();
-                    sweep_slow<T, WPS>(ap, k, i, pos, false, true, maxid, ncls, ph_last, ph_cur);
-                    if (sh.misc[M_FAIL]) { failed = 1; break; }
-                    if (tid == 0) {
-                        const int nclone_r = sh.misc[M_NCLONE];
-                        sh.stat[7] += 1;
-                        sh.stat[0] += maxid;                  // src/__pmdi.jl:187
-                        sh.stat[4] += ncls;
-                        sh.stat[2] += nclone_r;
-                        if (maxid + nclone_r > sh.stat[3]) sh.stat[3] = maxid + nclone_r;
-                        sh.kmaxid[k] = maxid + nclone_r; sh.kncls[k] = sh.misc[M_NCLS];
-                        sh.wk[k * 8 + WK_UPD] += sh.misc[M_ND]; sh.wk[k * 8 + WK_CLONE] += nclone_r;
-                    }
-                    __syncthreads();
-                }
-                continue;
-            }
 
             PH(1);
             const int ns0_cur = ns0_next;
@@ -2110,19 +2154,6 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
 
         // -- Phi_upweight! (src/misc.jl:50-59)
         PH(9);
-        if (replay) {
-            // (the settled-chain kernel added it; the next step's observation row and reference label, which a step fetches for its successor)
-            replay = false;
-            lw_uniform = false;
-            const DsetDev &d0 = dsb[0];
-            if (pos + 1 < n) {
-                if (tid < d0.D) {
-                    if (d0.kind == K_GAUSSIAN) nx = glob(d0.xf)[(size_t)i_next * d0.D + tid]; else nxi = glob(d0.xi)[(size_t)i_next * d0.D + tid];
-                }
-                ns0_next = s_in[i_next];
-            }
-            __syncthreads();
-        } else
         if (XSPLIT) {
             // Hand-off between the K workgroups of the chain (one per swept observation): every workgroup has stored its dataset's
             // records with agent-scope (sc1, write-through) stores; each storing wave drains them, the workgroup meets, one lane
@@ -2275,7 +2306,7 @@ __global__ void __launch_bounds__(T, WPS) pmdi_sweep_kernel(const SweepArgs *__r
     PH(11);
     sweep_final<T>(ap);
     PH(12);
-    if (tid == 0 && kd0 == 0) a.cost[chain] = (resuming ? a.cost[chain] : 0) + (clock64() - t_start);
+    if (tid == 0 && kd0 == 0) a.cost[chain] = ((a.resume_mode != 0 && a.resume != nullptr) ? a.cost[chain] : 0) + (clock64() - t_start);
     if (a.phase && tid == 0) {
         sh.ph[14] = clock64() - ph_t0; sh.ph[15] = wall_clock64() - ph_r0;
     }

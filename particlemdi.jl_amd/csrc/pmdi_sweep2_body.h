@@ -30,6 +30,7 @@
 // its own: that is how the test suite runs this source on a CPU, see tests/emu/.  The product build never does.)
 #ifndef PM2_LANE_API_PROVIDED
 #define PM2_DEV __device__ __forceinline__
+#define PM2_COLD __device__ __noinline__          // out of line: a cold path must not cost the sweep loop registers
 #define PM2_HD inline __host__ __device__
 extern __shared__ __attribute__((aligned(16))) unsigned char pm2_smem_[];
 #define PM2_SMEM (pm2_smem_)
@@ -383,6 +384,11 @@ struct RegArr<Tp, 1> {
 // (the levels per feature of a Categorical dataset's pool rows: read here, ahead of the layout shorthand `L` of the struct below)
 template <class Ds> PM2_DEV int ds_levels(const Ds &d) { return d.L; }
 
+template <int K, int PPL, int NW> struct Sweep2;
+// (cold paths of the sweep as out-of-line functions on a COPY of the sweep's per-lane state: inlined, their code cost the sweep loop
+// twenty spilled registers)
+template <int K, int PPL, int NW> PM2_COLD void hand_over_cold(Sweep2<K, PPL, NW> s, long long pos, int fcode, long long t_start);
+
 // ------------------------------------------------------------------------------------------------------------------------------------
 template <int K, int PPL, int NW>
 struct Sweep2 {
@@ -392,7 +398,11 @@ struct Sweep2 {
     RegArr<double, PPL> lw;
     static constexpr int NCP = (PPL + 1) / 2;
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
-    RegArr<u64, K> cslp;        // class slot of the lane's particles, one word per dataset, CSB bits each: bit offset CSB * u
+    // class slot of the lane's particles, one word per dataset (32 bits while they fit), CSB bits each: bit offset CSB * u
+    template <bool Wide, class Dummy = void> struct CslWord { typedef unsigned type; };
+    template <class Dummy> struct CslWord<true, Dummy> { typedef u64 type; };
+    typedef typename CslWord<(CSB * PPL > 32)>::type csl_t;
+    RegArr<csl_t, K> cslp;
     static_assert(CSB * PPL <= 64 && (1 << CSB) >= CLSMAX, "class slots of a lane's particles of one dataset must fit one 64-bit word");
     RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
 #ifdef PM2_DETAIL_TIMERS
@@ -444,8 +454,8 @@ struct Sweep2 {
     {
         lw.set(u, x);
     }
-    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp[k] >> (CSB * u)) & (u64)((1 << CSB) - 1)); }
-    PM2_DEV void csl_put(int k, int u, int r) { const int sh = CSB * u; cslp.set(k, (cslp[k] & ~((u64)((1 << CSB) - 1) << sh)) | ((u64)r << sh)); }
+    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp[k] >> (CSB * u)) & (csl_t)((1 << CSB) - 1)); }
+    PM2_DEV void csl_put(int k, int u, int r) { const int sh = CSB * u; cslp.set(k, (csl_t)((cslp[k] & ~((csl_t)((1 << CSB) - 1) << sh)) | ((csl_t)r << sh))); }
     PM2_DEV DV view(int k) const
     {
         DV v;
@@ -1891,7 +1901,7 @@ struct Sweep2 {
 #pragma unroll
             for (int j = 0; j < NCP; ++j) colp.set(k * NCP + j, 0u);
 #pragma unroll
-        for (int k = 0; k < K; ++k) cslp.set(k, 0ull);
+        for (int k = 0; k < K; ++k) cslp.set(k, (csl_t)0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) { c_mu.set(s, 0.0); c_lam.set(s, 1.0); }
         PM2_BARRIER();
@@ -2099,7 +2109,7 @@ struct Sweep2 {
                 }
                 col_put(k, ck);
             }
-            if (fcode) { hand_over(pos, fcode, t_start); return; }
+            if (__builtin_expect(fcode != 0, 0)) { hand_over_cold(*this, pos, fcode, t_start); return; }      // (out of line, on a copy of the lane's state)
             double ess = (double)P;
             if (!lw_flat) {
                 double sa = 0.0, sq = 0.0;
@@ -2315,5 +2325,10 @@ struct Sweep2 {
 #undef CLS
 #undef L
 };
+
+template <int K, int PPL, int NW> PM2_COLD void hand_over_cold(Sweep2<K, PPL, NW> s, long long pos, int fcode, long long t_start)
+{
+    s.hand_over(pos, fcode, t_start);
+}
 
 }  // namespace pmdi_s2

@@ -9,6 +9,7 @@
 
 #define PM2_LANE_API_PROVIDED 1
 #define PM2_DEV inline
+#define PM2_COLD __attribute__((noinline))
 #define PM2_HD inline
 #define PM2_SMEM (wavesim::lds_base())
 #define PM2_TID() (wavesim::tid())

@@ -44,7 +44,9 @@ def _spills(extra=()):
 
 
 def test_spill_budget_of_the_sweep_kernel_builds():
-    spills = _spills()
+    # (-DPMDI_NO_RESUME: without the out-of-line functions that carry on a chain the settled-chain kernel handed over -- cold code whose
+    # own spills the compiler folds into the kernel's figure; what is budgeted is the step loop)
+    spills = _spills(["-DPMDI_NO_RESUME"])
     for variant, limit in BUDGET.items():
         assert variant in spills, (variant, sorted(spills))
         assert spills[variant] <= limit, f"pmdi_sweep_kernel<{variant}> spills {spills[variant]} VGPRs (budget {limit})"
