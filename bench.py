@@ -374,6 +374,7 @@ def main():
             "obs_particles_per_sec": total_iters * n_s * P / dt,
             "burnin_iters_per_sec": (burnin * C * world / burnin_s) if burnin else None,
             "sweep_kernel_ms": kernel_ms,
+            "sweep_kernel_ms_each": [round(float(a.elapsed_time(b)), 1) for a, b in events],
             "allgather_ms": allgather_ms, "allgather_bytes_per_rank": (int(samples.numel()) if allgather_ms is not None else None),
             "sweep_only_iters_per_sec": C * world / (kernel_ms * 1e-3),
             "chain_slot_busy_frac": float(chain_s.sum() / (min(C * (K if sw.split else 1), (2 if sw.lds_bytes <= 80 * 1024 - 256 else 1) * 256) * kernel_ms * 1e-3))

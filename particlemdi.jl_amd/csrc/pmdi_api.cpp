@@ -135,6 +135,7 @@ struct pmdi_handle {
     // swept by 256-thread workgroups on a second stream, concurrently with the wide workgroups of the rest
     bool split = false;
     int l_terms_cap = 0, l_pid_lds = 0, l_pp_lds = 0, l_col_lds = 0;
+    int r_terms_cap = 0, r_pid_lds = 0, r_pp_lds = 0, r_col_lds = 0;     // the general kernel's LDS layout at the settled-chain kernel's workgroup width (hand-over in place)
     long long light_ids = 0;
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
@@ -338,29 +339,28 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
         al.terms_cap = h->l_terms_cap; al.pid_lds = h->l_pid_lds; al.pp_lds = h->l_pp_lds; al.col_lds = h->l_col_lds;
         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
         if (h->s2_ok) {
-            // the light chains go to the settled-chain kernel; the ones it gives back (a step that does not fit its tables) are
-            // swept again, from the start, by the general kernel right behind it on the same stream
+            // the light chains go to the settled-chain kernel.  A chain whose step does not fit its tables is carried on from that
+            // observation by the general kernel's code in the same workgroup: the argument block holds the general kernel's LDS
+            // layout for that workgroup width
+            al.terms_cap = h->r_terms_cap; al.pid_lds = h->r_pid_lds; al.pp_lds = h->r_pp_lds; al.col_lds = h->r_col_lds;
             int idx;
             SweepArgs *slot = next_slot(h, h->stream2, &idx);
             e = pmdi_launch_sweep2(al, (SweepArgs *)h->d_args4.p, C, h->stream2, slot);
             if (e == hipSuccess && idx >= 0) { e = hipEventRecord(h->ring_ev[idx], h->stream2); h->ring_used[idx] = true; }
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (settled chains): %s", hipGetErrorString(e));
-            SweepArgs ar = al;
-            ar.group_flag = nullptr; ar.requeue_only = 1;
-            int Tr = 256;
-            if (h->s2_continue) {
-                // ... from the observation where that kernel stopped (its hand-over record): one workgroup per chain -- the wide build
-                // when a lane of the 256-thread one would carry eight particles
-                ar.resume_mode = 1;
-                if (h->cfg.P > 1024) { Tr = h->T; ar.terms_cap = h->terms_cap; ar.pid_lds = h->pid_lds; ar.pp_lds = h->pp_lds; ar.col_lds = h->col_lds; }
-            } else if (h->cfg.K > 1 && h->d_xcnt.p && !(getenv("PMDI_REQUEUE_KSPLIT") && atoi(getenv("PMDI_REQUEUE_KSPLIT")) == 0)) {
-                // ... from the start, with one workgroup per dataset when the model has several (the latency form: a chain that is swept
-                // twice should at least be swept fast the second time -- it is the tail of the whole sweep)
-                ar.ksplit = 1;
-                HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, h->stream2));
+            if (!h->s2_continue) {
+                // (PMDI_CONTINUE=0, the round-3 behaviour kept for A/B runs: no hand-over record; the chains that kernel gives back are
+                // swept again FROM THE START by the general kernel right behind it -- with one workgroup per dataset when the model has several)
+                SweepArgs ar = al;
+                ar.group_flag = nullptr; ar.requeue_only = 1;
+                ar.terms_cap = h->l_terms_cap; ar.pid_lds = h->l_pid_lds; ar.pp_lds = h->l_pp_lds; ar.col_lds = h->l_col_lds;
+                if (h->cfg.K > 1 && h->d_xcnt.p && !(getenv("PMDI_REQUEUE_KSPLIT") && atoi(getenv("PMDI_REQUEUE_KSPLIT")) == 0)) {
+                    ar.ksplit = 1;
+                    HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, h->stream2));
+                }
+                e = launch_one(h, ar, (SweepArgs *)h->d_args5.p, C, 256, h->stream2);
+                if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (chains given back by the settled-chain kernel): %s", hipGetErrorString(e));
             }
-            e = launch_one(h, ar, (SweepArgs *)h->d_args5.p, C, Tr, h->stream2);
-            if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (chains given back by the settled-chain kernel): %s", hipGetErrorString(e));
         } else {
             e = launch_maybe_batched(h, al, (SweepArgs *)h->d_args2.p, C, 256, h->stream2);
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (light group): %s", hipGetErrorString(e));
@@ -662,6 +662,12 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         if (h->split) {
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
         }
+        if (h->split && h->s2_ok) {
+            const int thr = pmdi_sweep2_threads(K, P);
+            if (thr == 256) { h->r_terms_cap = h->l_terms_cap; h->r_pid_lds = h->l_pid_lds; h->r_pp_lds = h->l_pp_lds; h->r_col_lds = h->l_col_lds; }
+            else if (configure(thr, h->r_terms_cap, h->r_pid_lds, h->r_pp_lds, h->r_col_lds)) h->s2_continue = false;
+        }
+        if (!h->split) h->s2_ok = false;
         if (h->split) {
             // the slow chains bound the launch, so their workgroups must not queue behind the many
             // light ones: light launch on a low-priority stream, heaviest chains on a high-priority one

@@ -1,6 +1,19 @@
 // pmdi_sweep2.hip -- the conditional-SMC sweep for settled chains as a gfx950 kernel: the device code is pmdi_sweep2_body.h (design
 // notes there and in DESIGN.md); this file instantiates it per (datasets, particles per lane) and launches it.
 // Compile with -ffp-contract=off.
+// The general sweep kernel's device code: a chain this kernel's tables no longer hold is carried on by it IN PLACE -- same workgroup,
+// same dynamic LDS (the launch asks for the larger of the two layouts), from the observation of the hand-over -- instead of
+// waiting for another launch behind this one.
+// (-DPM2_NO_RESUME_GENERAL: tests/test_build_budget.py measures this kernel's own spills -- the compiler's figure folds callees in)
+#ifndef PM2_NO_RESUME_GENERAL
+#include "pmdi_sweep_body.h"
+template <int K, int NW>
+__device__ __noinline__ void pmdi_resume_general(const SweepArgs *ap)
+{
+    pmdi_sweep_body<64 * NW, 2, K == 1, false, true>(ap);
+}
+#define PM2_RESUME_GENERAL(K_, NW_, ap_) pmdi_resume_general<K_, NW_>(ap_)
+#endif
 #include "pmdi_sweep2_body.h"
 
 namespace {
@@ -65,14 +78,24 @@ bool pmdi_sweep2_supports(int K, int N, int P, int Dmax, long long cap)
     return K >= 1 && K <= pmdi_s2::KMAX2 && N >= 2 && N <= 64 && Dmax <= 64 && kernel_for(K, P, &nw) != nullptr;
 }
 
+// dynamic LDS of a launch: this kernel's layout, or the general kernel's for the same workgroup width when a handed-over chain is
+// carried on in place and that layout is the larger one
+static size_t launch_lds(const SweepArgs &a, int nw)
+{
+    size_t lds = (size_t)a.s2.total;
+    if (a.resume) { const size_t g = pmdi_sweep_lds_bytes(a, 64 * nw); if (g > lds) lds = g; }
+    return lds;
+}
+
 hipError_t pmdi_sweep2_blocks_per_cu(const SweepArgs &a, int *blocks)
 {
     int nw = 0;
     const void *fn = kernel_for(a.K, a.P, &nw);
     if (!fn) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.s2.total);
+    const size_t lds = launch_lds(a, nw);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fn, 64 * nw, (size_t)a.s2.total);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, fn, 64 * nw, lds);
 }
 
 hipError_t pmdi_launch_sweep2(const SweepArgs &a_in, SweepArgs *d_args, int n_chains, hipStream_t stream, SweepArgs *staging)
@@ -82,7 +105,8 @@ hipError_t pmdi_launch_sweep2(const SweepArgs &a_in, SweepArgs *d_args, int n_ch
     int nw = 0;
     const void *fn = kernel_for(a.K, a.P, &nw);
     if (!fn) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, a.s2.total);
+    const size_t lds = launch_lds(a, nw);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const SweepArgs *src = &a;
     if (staging) { *staging = a; src = staging; }
@@ -90,7 +114,7 @@ hipError_t pmdi_launch_sweep2(const SweepArgs &a_in, SweepArgs *d_args, int n_ch
     if (e != hipSuccess) return e;
     const SweepArgs *ap = d_args;
     void *args[] = {(void *)&ap};
-    e = hipLaunchKernel(fn, dim3((unsigned)n_chains), dim3(64u * (unsigned)nw), args, (size_t)a.s2.total, stream);
+    e = hipLaunchKernel(fn, dim3((unsigned)n_chains), dim3(64u * (unsigned)nw), args, lds, stream);
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }

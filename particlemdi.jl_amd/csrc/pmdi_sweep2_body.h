@@ -1920,7 +1920,8 @@ struct Sweep2 {
             ns0_next = PM2_G(const int, a.s_in)[((size_t)chain * K + wave) * n + i_next];
         }
         pend_slot = -1; pend_g = 0.0;
-        int failed = 0;
+        int failed = 0, handed = 0;
+        long long pos_handed = 0;
         for (long long pos = n1 - 1; pos < n; ++pos) {
             PM2_LAUNDER(ap, SweepArgs);
             PM2_FRESH_VGPR(tid); PM2_FRESH_VGPR(lane);
@@ -2109,7 +2110,7 @@ struct Sweep2 {
                 }
                 col_put(k, ck);
             }
-            if (__builtin_expect(fcode != 0, 0)) { hand_over_cold(*this, pos, fcode, t_start); return; }      // (out of line, on a copy of the lane's state)
+            if (__builtin_expect(fcode != 0, 0)) { handed = fcode; pos_handed = pos; break; }       // (the calls are made outside the loop)
             double ess = (double)P;
             if (!lw_flat) {
                 double sa = 0.0, sq = 0.0;
@@ -2146,6 +2147,17 @@ struct Sweep2 {
                 tr[0] = ess; tr[1] = res ? 1.0 : 0.0;
                 for (int k = 0; k < K; ++k) { tr[2 + k] = (double)view(k).dsc()[DS_MAXID]; tr[2 + K + k] = (double)view(k).dsc()[DS_NCLS]; }
             }
+        }
+        if (handed) {
+            hand_over_cold(*this, pos_handed, handed, t_start);      // (out of line, on a copy of the lane's state)
+#ifdef PM2_RESUME_GENERAL
+            // ... and the general kernel's code carries the chain on, in this workgroup (what was written above is read back by other
+            // lanes of it: every store is out and visible before anybody goes on)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            PM2_BARRIER();
+            PM2_RESUME_GENERAL(K, NW, ap_);
+#endif
+            return;
         }
         if (failed) {
             if (tid == 0) {
@@ -2250,7 +2262,7 @@ struct Sweep2 {
             st[5] = s[5]; st[6] = 0; st[7] = 0;
             PM2_G(int, a.resume)[(size_t)chain * 16] = (int)pos;
             PM2_G(int, a.resume)[(size_t)chain * 16 + 1] = done_mask;
-            PM2_G(int, a.requeue)[chain] = 1;
+            PM2_G(int, a.requeue)[chain] = 0;             // (not for another launch: this workgroup carries the chain on)
             if (!a.err_keep) PM2_G(int, a.err)[chain] = 0;
             if (a.handed) PM2_G(int, a.handed)[chain] = a.sweep_no;
             if (a.requeue_total) {

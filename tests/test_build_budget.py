@@ -44,17 +44,16 @@ def _spills(extra=()):
 
 
 def test_spill_budget_of_the_sweep_kernel_builds():
-    # (-DPMDI_NO_RESUME: without the out-of-line functions that carry on a chain the settled-chain kernel handed over -- cold code whose
-    # own spills the compiler folds into the kernel's figure; what is budgeted is the step loop)
-    spills = _spills(["-DPMDI_NO_RESUME"])
+    spills = _spills()
     for variant, limit in BUDGET.items():
         assert variant in spills, (variant, sorted(spills))
         assert spills[variant] <= limit, f"pmdi_sweep_kernel<{variant}> spills {spills[variant]} VGPRs (budget {limit})"
 
 
 SRC2 = os.path.join(ROOT, "particlemdi.jl_amd", "csrc", "pmdi_sweep2.hip")
-BUDGET2 = 100         # VGPR spill slots of any <K, PPL, NW> build of the settled-chain kernel (256 registers, two waves per SIMD).
-#                       Round 4 (three cluster types, 4- and 8-wave workgroups) measures 24..99; <4, 4, 4> -- the headline's -- 69.
+BUDGET2 = 125         # VGPR spill slots of any <K, PPL, NW> build of the settled-chain kernel (256 registers, two waves per SIMD), measured
+#                       without the general kernel's code it calls to carry a handed-over chain on (-DPM2_NO_RESUME_GENERAL: cold, out of
+#                       line, and the compiler's figure folds callees in).  Round 4 (three cluster types, 4- and 8-wave workgroups, hand-over).
 #                       Round 3 measures 19..82: 0..25 until the statistics phase shared by all four waves (help_stats) was added -- it runs
 #                       with every lane's particle state live and costs ~55 slots (15 of the 40 scratch stores of <4, 4> are loop
 #                       invariants parked once before the sweep loop), and it still made the HL sweep 3 % faster (the slowest chains 10 %).
@@ -66,7 +65,7 @@ def test_spill_budget_of_the_settled_chain_kernel_builds():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     with tempfile.TemporaryDirectory() as tmp:
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
-                            "--cuda-device-only", "-c", SRC2, "-o", os.path.join(tmp, "x.o"),
+                            "--cuda-device-only", "-c", SRC2, "-o", os.path.join(tmp, "x.o"), "-DPM2_NO_RESUME_GENERAL",
                             "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     cur, seen = None, {}
@@ -81,4 +80,4 @@ def test_spill_budget_of_the_settled_chain_kernel_builds():
     assert len(seen) == 16, sorted(seen)
     for variant, n in seen.items():
         assert n <= BUDGET2, f"pmdi_sweep2_kernel<{variant[0]}, {variant[1]}, {variant[2]}> spills {n} VGPRs (budget {BUDGET2})"
-    assert seen[(4, 4, 4)] <= 75, seen[(4, 4, 4)]
+    assert seen[(4, 4, 4)] <= 110, seen[(4, 4, 4)]
