@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PMDI_ABI_VERSION 1
+#define PMDI_ABI_VERSION 2
 #define PMDI_KMAX 8 /* datasets per handle */
 /* Other limits of this build (pmdi_create rejects what exceeds them with PMDI_E_ARG / PMDI_E_DATA): N <= 255 clusters (the reference:
  * N <= n, src/pmdi.jl:54; labels travel as bytes), categorical levels <= 4096 per feature (host-built log tables), P <= 1048575. */
@@ -60,6 +60,36 @@ typedef struct {
     const int64_t *xi;
 } pmdi_dataset;
 
+/* Kernel-selection and sizing knobs of pmdi_create (results never depend on them).  Every field: -1 = automatic.  The library
+ * itself never reads the environment -- one handle's behaviour depends on what its creator passed, on nothing process-wide.
+ * A caller that wants the PMDI_* environment variables (the test-suite, bench.py and the profiling scripts do, through
+ * particlemdi.jl_amd/_lib.py) fills the struct with pmdi_tuning_from_env() and passes it in pmdi_config.tuning; NULL = all automatic. */
+typedef struct {
+    int32_t settled;        /* PMDI_SETTLED        0 never / 1 light chains after their first sweep (automatic) / 2 every chain in every
+                             *                     sweep (tests) use the settled-chain kernel where the handle has it: pmdi_settled_kernel() */
+    int32_t continue_inplace; /* PMDI_CONTINUE     1 (automatic): a chain that kernel cannot carry is carried on by the general kernel's code in
+                             *                     the same workgroup from that observation; 0: swept again from the start behind the launch */
+    int32_t sticky;         /* PMDI_STICKY         sweeps a handed-over chain starts on the general kernel afterwards (automatic 3) */
+    int32_t light_ids;      /* PMDI_LIGHT_IDS      a chain whose last sweep met at most this many live clusters per step is "light"
+                             *                     (automatic: that kernel's LDS id capacity where the handle has it, else 40) */
+    int32_t s2_cols, s2_idcap, s2_cls; /* PMDI_S2_COLS / _IDCAP / _CLS  columns, cluster ids, particle classes per dataset its LDS tables hold
+                             *                     (automatic 64 / 128 / 32, shrunk by pmdi_create to the LDS budget) */
+    int32_t ksplit;         /* PMDI_KSPLIT         K > 1: 0 one workgroup per chain (throughput form) / 1 K cooperating workgroups per chain
+                             *                     (latency form); automatic: split while n_chains * K workgroups are resident at once */
+    int32_t requeue_ksplit; /* PMDI_REQUEUE_KSPLIT (continue_inplace = 0 only) 0: re-run given-back chains in one workgroup instead of K */
+    int32_t split;          /* PMDI_SPLIT          0: one launch per sweep instead of the heaviest / heavy / light launches */
+    int32_t heavy_threads;  /* PMDI_HEAVY_T        workgroup width of the heavy group (512 or 1024) */
+    int32_t two_per_cu;     /* PMDI_TWO_PER_CU     0: 256-register builds everywhere (one wide chain per CU) */
+    int32_t very_heavy;     /* PMDI_VERY_HEAVY     how many of the heaviest chains get a CU each (automatic: 0 with the settled-chain kernel, else 128) */
+    int32_t start_gate;     /* PMDI_START_GATE     0: do not hold the heavy / light launches until the heaviest chains' workgroups are placed */
+    int32_t terms_cap;      /* PMDI_TERMS_CAP      LDS doubles for the per-feature terms */
+    int32_t lds_target;     /* PMDI_LDS_TARGET     LDS bytes per workgroup above which the per-particle tables move to global memory */
+    int32_t phase_timers;   /* PMDI_PHASE_TIMERS   1: per-stage shader-clock timers (pmdi_phase_timers) */
+    int32_t profiled;       /* 1: a counter-collecting profiler is attached (rocprofv3 --pmc runs the queues one kernel at a time: a launch
+                             *                     that waits for another launch's workgroups would never start -- no start gate then) */
+    int32_t reserved[6];    /* -1 */
+} pmdi_tuning;
+
 typedef struct {
     int32_t abi_version;   /* PMDI_ABI_VERSION */
     int32_t device;        /* HIP device ordinal */
@@ -74,6 +104,7 @@ typedef struct {
     int64_t pool_cap;      /* cluster pool ids per dataset; 0 = N*P+1 (src/pmdi.jl:140) */
     int32_t block_threads; /* 0 = choose (and split the chains of a sweep into concurrent launches by weight); else 128/256/512/1024 */
     int32_t reserved;
+    const pmdi_tuning *tuning; /* NULL = all automatic (read during pmdi_create only) */
 } pmdi_config;
 
 typedef struct pmdi_handle pmdi_handle;
@@ -94,27 +125,11 @@ typedef struct {
  * marginal of :120-128.  Copies the data to the device (row-major). */
 int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handle **out);
 
-/* Tuning knobs read from the environment at pmdi_create (results never depend on them):
- *   PMDI_SPLIT=0          one launch per sweep instead of the heaviest / heavy / light launches (block_threads = 0)
- *   PMDI_LIGHT_IDS        a chain whose last sweep met at most this many live clusters per step is "light" (default: the LDS id
- *                         capacity of the settled-chain kernel, 128, where the handle has that kernel; else 40)
- *   PMDI_SETTLED=0/2      never / from the first sweep on use the settled-chain kernel (default: all-Gaussian handles with
- *                         2 <= K <= 4, N <= 64, D <= 64, P in {256, 512, 1024}, after a chain's first sweep; pmdi_settled_kernel())
- *   PMDI_S2_COLS=64, PMDI_S2_IDCAP=128   columns / cluster ids its LDS tables hold before they continue in the arena (shrunk by
- *                         pmdi_create until two workgroups fit a CU)
- *   PMDI_REQUEUE_KSPLIT=0 re-run the chains that kernel gives back in one workgroup instead of K
- *   PMDI_STICKY=3         sweeps a given-back chain stays with the general kernel (HL, 2 048 chains: 0 -> 1 163, 3 -> 1 164, 10 -> 1 130 it/s)
- *   PMDI_VERY_HEAVY=128   how many of the heaviest chains get a CU each (default 0 on handles with the settled-chain kernel)
- *   PMDI_HEAVY_T          workgroup width of the heavy group (512 or 1024)
- *   PMDI_TWO_PER_CU=0     256-register builds everywhere (one wide chain per CU)
- *   PMDI_TERMS_CAP        LDS doubles for the per-feature terms
- *   PMDI_PHASE_TIMERS=1   per-stage shader-clock timers (pmdi_phase_timers)
- *   PMDI_KSPLIT=0/1       K > 1: one workgroup per chain (throughput form) / K cooperating workgroups per chain, one per
- *                         dataset, meeting once per swept observation (latency form).  Default: split while n_chains * K
- *                         workgroups are resident at once.  pmdi_is_split() tells which form a handle uses.
- *   PMDI_LDS_TARGET       LDS bytes per workgroup above which the per-particle tables move to global memory
- *   PMDI_START_GATE=0     do not hold the heavy / light launches of a sweep until the heaviest chains' workgroups have been
- *                         placed (switched off by itself under rocprofv3: counter collection serialises the queues) */
+/* every field of *t = -1 (automatic) */
+void pmdi_tuning_default(pmdi_tuning *t);
+/* pmdi_tuning_default, then every PMDI_* environment variable that is set (names beside the fields above); `profiled` = a rocprof
+ * tool library is preloaded.  The only place of the library that reads the environment, and only when the caller asks. */
+void pmdi_tuning_from_env(pmdi_tuning *t);
 int pmdi_destroy(pmdi_handle *h);
 const char *pmdi_last_error(void);
 int pmdi_abi_version(void);

@@ -21,7 +21,7 @@ GAUSSIAN, CATEGORICAL, NEGBINOM = 0, 1, 2
 KIND_BY_NAME = {"gaussian": GAUSSIAN, "categorical": CATEGORICAL, "negbinom": NEGBINOM,
                 "GaussianCluster": GAUSSIAN, "CategoricalCluster": CATEGORICAL,
                 "NegBinomCluster": NEGBINOM}
-ABI_VERSION = 1
+ABI_VERSION = 2
 KMAX = 8
 
 EXPORTS = [
@@ -35,7 +35,7 @@ EXPORTS = [
     "pmdi_csv_open", "pmdi_csv_write_row", "pmdi_csv_write_gibbs", "pmdi_csv_open_features", "pmdi_csv_write_flags",
     "pmdi_csv_close", "pmdi_csv_read_allocations", "pmdi_format_float64", "pmdi_work_counters", "pmdi_shader_clock_hz", "pmdi_is_split",
     "pmdi_comm_unique_id", "pmdi_comm_init_rank", "pmdi_comm_init_all", "pmdi_comm_destroy", "pmdi_comm_rank", "pmdi_comm_size",
-    "pmdi_allgather_samples", "pmdi_settled_kernel", "pmdi_chain_swept_by",
+    "pmdi_allgather_samples", "pmdi_settled_kernel", "pmdi_chain_swept_by", "pmdi_tuning_default", "pmdi_tuning_from_env",
 ]
 
 
@@ -95,11 +95,20 @@ class _Dataset(C.Structure):
                 ("xf", C.POINTER(C.c_double)), ("xi", C.POINTER(C.c_int64))]
 
 
+class _Tuning(C.Structure):
+    """pmdi_tuning (include/pmdi_hip.h): kernel-selection knobs, -1 = automatic.  The library never reads the environment by itself;
+    this wrapper asks it to (pmdi_tuning_from_env) so that the PMDI_* variables keep working for tests, bench.py and the scripts."""
+    _fields_ = [(name, C.c_int32) for name in (
+        "settled", "continue_inplace", "sticky", "light_ids", "s2_cols", "s2_idcap", "s2_cls", "ksplit", "requeue_ksplit", "split",
+        "heavy_threads", "two_per_cu", "very_heavy", "start_gate", "terms_cap", "lds_target", "phase_timers", "profiled")] + [("reserved", C.c_int32 * 6)]
+
+
 class _Config(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("K", C.c_int32),
                 ("N", C.c_int32), ("P", C.c_int32), ("n_chains", C.c_int32), ("n", C.c_int64),
                 ("seed", C.c_uint64), ("q1_mode", C.c_int32), ("q2_mode", C.c_int32),
-                ("pool_cap", C.c_int64), ("block_threads", C.c_int32), ("reserved", C.c_int32)]
+                ("pool_cap", C.c_int64), ("block_threads", C.c_int32), ("reserved", C.c_int32),
+                ("tuning", C.POINTER(_Tuning))]
 
 
 class SweepStats(C.Structure):
@@ -186,6 +195,10 @@ def lib():
     L.pmdi_settled_kernel.argtypes = [vp, vp]
     L.pmdi_chain_swept_by.restype = C.c_int
     L.pmdi_chain_swept_by.argtypes = [vp, vp]
+    L.pmdi_tuning_default.restype = None
+    L.pmdi_tuning_default.argtypes = [C.POINTER(_Tuning)]
+    L.pmdi_tuning_from_env.restype = None
+    L.pmdi_tuning_from_env.argtypes = [C.POINTER(_Tuning)]
     L.pmdi_shader_clock_hz.restype = i64
     L.pmdi_shader_clock_hz.argtypes = [vp]
     L.pmdi_work_counters.restype = C.c_int
@@ -244,7 +257,8 @@ class Sweeper:
     pmdi()'s per-iteration sweep (src/pmdi.jl:165-171, 188-350, 354-370)."""
 
     def __init__(self, data, kinds, N, P, n_chains=1, seed=0, device=0, q1_mode=0, q2_mode=0,
-                 pool_cap=0, block_threads=0):
+                 pool_cap=0, block_threads=0, tuning=None):
+        """tuning: dict of pmdi_tuning fields (include/pmdi_hip.h) that override the PMDI_* environment variables for this handle."""
         L = lib()
         self.K = len(data)
         if self.K > KMAX:
@@ -270,8 +284,12 @@ class Sweeper:
                 self._keep.append(xi)
                 ds[k].xi = xi.ctypes.data_as(C.POINTER(C.c_int64))
         self.device = int(device)
+        tun = _Tuning()
+        L.pmdi_tuning_from_env(C.byref(tun))
+        for name, value in (tuning or {}).items():        # explicit knobs win over the environment
+            setattr(tun, name, int(value))
         cfg = _Config(ABI_VERSION, device, self.K, self.N, self.P, self.C, self.n, int(seed),
-                      q1_mode, q2_mode, int(pool_cap), int(block_threads), 0)
+                      q1_mode, q2_mode, int(pool_cap), int(block_threads), 0, C.pointer(tun))
         h = C.c_void_p()
         _check(L.pmdi_create(C.byref(cfg), ds, C.byref(h)))
         self.h = h

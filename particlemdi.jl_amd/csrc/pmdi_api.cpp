@@ -127,6 +127,7 @@ int pmdi_set_error(int code, const char *fmt, ...)
 
 struct pmdi_handle {
     pmdi_config cfg{};
+    pmdi_tuning tun{};           // the creator's knobs (a copy: cfg.tuning is not kept), -1 = automatic
     int T = 0;
     long long cap = 0;
     int Dmax = 0, sumD = 0, npairs = 1;
@@ -354,7 +355,7 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
                 SweepArgs ar = al;
                 ar.group_flag = nullptr; ar.requeue_only = 1;
                 ar.terms_cap = h->l_terms_cap; ar.pid_lds = h->l_pid_lds; ar.pp_lds = h->l_pp_lds; ar.col_lds = h->l_col_lds;
-                if (h->cfg.K > 1 && h->d_xcnt.p && !(getenv("PMDI_REQUEUE_KSPLIT") && atoi(getenv("PMDI_REQUEUE_KSPLIT")) == 0)) {
+                if (h->cfg.K > 1 && h->d_xcnt.p && h->tun.requeue_ksplit != 0) {
                     ar.ksplit = 1;
                     HIP_TRY(hipMemsetAsync(h->d_xcnt.p, 0, (size_t)C * 32 * 4, h->stream2));
                 }
@@ -387,6 +388,29 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
 extern "C" {
 
 const char *pmdi_last_error(void) { return g_err; }
+
+void pmdi_tuning_default(pmdi_tuning *t)
+{
+    if (!t) return;
+    int32_t *f = (int32_t *)t;
+    for (size_t i = 0; i < sizeof(pmdi_tuning) / sizeof(int32_t); ++i) f[i] = -1;
+}
+
+// The one place of the library that reads the environment -- and only when a caller asks for it.
+void pmdi_tuning_from_env(pmdi_tuning *t)
+{
+    if (!t) return;
+    pmdi_tuning_default(t);
+    auto env = [](const char *name, int32_t &field) { const char *v = getenv(name); if (v && *v) field = (int32_t)atoi(v); };
+    env("PMDI_SETTLED", t->settled); env("PMDI_CONTINUE", t->continue_inplace); env("PMDI_STICKY", t->sticky);
+    env("PMDI_LIGHT_IDS", t->light_ids); env("PMDI_S2_COLS", t->s2_cols); env("PMDI_S2_IDCAP", t->s2_idcap); env("PMDI_S2_CLS", t->s2_cls);
+    env("PMDI_KSPLIT", t->ksplit); env("PMDI_REQUEUE_KSPLIT", t->requeue_ksplit); env("PMDI_SPLIT", t->split);
+    env("PMDI_HEAVY_T", t->heavy_threads); env("PMDI_TWO_PER_CU", t->two_per_cu); env("PMDI_VERY_HEAVY", t->very_heavy);
+    env("PMDI_START_GATE", t->start_gate); env("PMDI_TERMS_CAP", t->terms_cap); env("PMDI_LDS_TARGET", t->lds_target);
+    if (getenv("PMDI_PHASE_TIMERS")) t->phase_timers = 1;
+    auto has = [](const char *name, const char *what) { const char *v = getenv(name); return v && strstr(v, what) != nullptr; };
+    t->profiled = (has("LD_PRELOAD", "rocprof") || has("ROCP_TOOL_LIBRARIES", "rocprof") || has("HSA_TOOLS_LIB", "rocprof")) ? 1 : 0;
+}
 int pmdi_abi_version(void) { return PMDI_ABI_VERSION; }
 
 int pmdi_destroy(pmdi_handle *h)
@@ -448,6 +472,9 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     pmdi_handle *h = new (std::nothrow) pmdi_handle();
     if (!h) return fail(PMDI_E_MEMORY, "out of host memory");
     h->cfg = *cfg;
+    if (cfg->tuning) h->tun = *cfg->tuning; else pmdi_tuning_default(&h->tun);
+    h->cfg.tuning = nullptr;
+    const pmdi_tuning &tn = h->tun;
     h->cap = cap;
     h->npairs = K > 1 ? K * (K - 1) / 2 : 1;
     int rc = 0;
@@ -529,10 +556,10 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
     }
     h->sumD = flag_off;
     h->T = cfg->block_threads ? cfg->block_threads : (P >= 2048 ? 1024 : (P > 256 ? 512 : 256));
-    if (!cfg->block_threads && h->T > 256 && getenv("PMDI_HEAVY_T")) h->T = atoi(getenv("PMDI_HEAVY_T"));   // tuning knob: width of the heavy group
+    if (!cfg->block_threads && h->T > 256 && tn.heavy_threads > 0) h->T = tn.heavy_threads;   // tuning knob: width of the heavy group
     if (h->T != 128 && h->T != 256 && h->T != 512 && h->T != 1024) return bail(fail(PMDI_E_ARG, "block_threads must be 128, 256, 512 or 1024"));
     {
-        auto env_int = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+        auto knob = [](int32_t v, int dflt) { return v >= 0 ? (int)v : dflt; };      // (-1 = automatic)
         // (a step whose particle classes' (class, label) items outgrow the LDS tables takes the general route through global memory;
         // one class always fits: N <= 255 < 384)
         if (N > (N > 32 ? PMDI_ITEM_CAP_BIGN : PMDI_ITEM_CAP)) return bail(fail(PMDI_E_ARG, "N=%d too large for the LDS tables", N));
@@ -545,13 +572,13 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         // split launch that is not resident at once goes out in residency-sized batches).  The history-permuting __pmdi mode
         // (q2_mode = 1) always keeps the single-workgroup form: its ancestor log is per chain.
         const bool ks_ok = K > 1 && cfg->q2_mode == 0 && (long long)K * n < (1LL << 27);
-        const int ks_env = env_int("PMDI_KSPLIT", -1);
+        const int ks_env = tn.ksplit;
         h->ksplit = (ks_ok && ks_env != 0) ? 1 : 0;      // tentative: the layout below is the split form's
-        h->phase_on = getenv("PMDI_PHASE_TIMERS") != nullptr;
+        h->phase_on = tn.phase_timers > 0;
         // per workgroup width: LDS term buffer (at least P doubles for the resampling weights, the
         // per-wave CDF exchange areas, a few rows of 2*D+1) and which per-particle tables fit LDS
         auto configure = [&](int T, int &terms_cap, int &pid_lds, int &pp_lds, int &col_lds) -> int {
-            int tc = env_int("PMDI_TERMS_CAP", 1024);
+            int tc = knob(tn.terms_cap, 1024);
             if (tc < P) tc = P;
             if (tc < (T / 64) * (N > 64 ? 512 : 128)) tc = (T / 64) * (N > 64 ? 512 : 128);   // per-wave exchange areas of the CDF stage
             if (tc < 4 * (2 * h->Dmax + 1)) tc = 4 * (2 * h->Dmax + 1);
@@ -565,7 +592,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             // Two chains per CU (<= 80 KiB each) hide each other's dependent latencies: +40 % aggregate throughput on the
             // headline workload even with the per-particle tables in global memory.  So: the largest set of per-particle
             // tables that still fits 80 KiB; if none does, one chain per CU with everything that fits 150 KiB in LDS.
-            const char *tgt = getenv("PMDI_LDS_TARGET");
+            const bool tgt = tn.lds_target >= 0;
             const size_t half = 80 * 1024 - 256;      // half a CU's 160 KiB, less the kernel's static LDS (256 bytes of reduction scratch)
             bool fits_half = false;
             if (!tgt) {
@@ -578,7 +605,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             }
             if (!fits_half) {
                 a.pid_lds = 1; a.pp_lds = 1; a.col_lds = col_ok;
-                const size_t lds_target = tgt ? (size_t)atoi(tgt) : (size_t)150 * 1024;
+                const size_t lds_target = tgt ? (size_t)tn.lds_target : (size_t)150 * 1024;
                 if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pid_lds = 0;   // class ids of K*P particles do not fit: global memory
                 if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.pp_lds = 0;    // nor does the per-particle step scratch
                 if (pmdi_sweep_lds_bytes(a, T) > lds_target) a.col_lds = 0;   // nor do the column indices
@@ -589,13 +616,13 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             return 0;
         };
         auto configure_wide = [&]() -> int {
-            h->two_per_cu = env_int("PMDI_TWO_PER_CU", 1);
+            h->two_per_cu = knob(tn.two_per_cu, 1);
             const int r = configure(h->T, h->terms_cap, h->pid_lds, h->pp_lds, h->col_lds);
             if (r) return r;
             // one chain per CU anyway: the 256-register build (no spills) instead of the register-capped one
             SweepArgs a;
             fill_sweep_common(h, a);
-            if (!getenv("PMDI_TWO_PER_CU") && pmdi_sweep_lds_bytes(a, h->T) > 80 * 1024 - 256) h->two_per_cu = 0;
+            if (tn.two_per_cu < 0 && pmdi_sweep_lds_bytes(a, h->T) > 80 * 1024 - 256) h->two_per_cu = 0;
             return 0;
         };
         if ((rc = configure_wide())) return bail(rc);
@@ -622,18 +649,18 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         {
             // (K = 1: three of its four waves would idle through the cluster phases -- cfg2 runs 2 812 it/s on the general kernel's
             // one-dataset build and 2 086 with this kernel; PMDI_SETTLED=2 forces it for the tests of its K = 1 instantiations)
-            bool ok = env_int("PMDI_SETTLED", 1) != 0 && (K >= 2 || env_int("PMDI_SETTLED", 1) == 2) && cfg->block_threads == 0 && !h->ksplit && cfg->q1_mode == 0 && cfg->q2_mode == 0 &&
+            bool ok = knob(tn.settled, 1) != 0 && (K >= 2 || knob(tn.settled, 1) == 2) && cfg->block_threads == 0 && !h->ksplit && cfg->q1_mode == 0 && cfg->q2_mode == 0 &&
                       pmdi_sweep2_supports(K, N, P, h->Dmax, cap);
             if (ok) {
                 const size_t budget = pmdi_sweep2_threads(K, P) > 256 ? (size_t)159 * 1024 : (size_t)80 * 1024;
-                int cols_l = env_int("PMDI_S2_COLS", 64), idcap = env_int("PMDI_S2_IDCAP", 128);
+                int cols_l = knob(tn.s2_cols, 64), idcap = knob(tn.s2_idcap, 128);
                 if (cols_l < 1) cols_l = 1;
                 if (cols_l > P) cols_l = P;
                 if (idcap < 8) idcap = 8;
                 if (idcap > 4096) idcap = 4096;
                 // particle classes per dataset the LDS tables hold: as many as the budget allows, 32 at most (a step with more hands the
                 // chain over to the general kernel: with N labels a single ambiguous observation fans one class out into up to N)
-                int cls = env_int("PMDI_S2_CLS", 32);
+                int cls = knob(tn.s2_cls, 32);
                 if (cls < 16) cls = 16;
                 if (cls > 32) cls = 32;
                 cls &= ~3;
@@ -649,16 +676,16 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
             h->s2_ok = ok;
         }
         // automatic width: split the chains of a sweep into a heavy and a light launch
-        h->split = cfg->block_threads == 0 && (h->T > 256 || h->s2_ok) && env_int("PMDI_SPLIT", 1) != 0;
+        h->split = cfg->block_threads == 0 && (h->T > 256 || h->s2_ok) && knob(tn.split, 1) != 0;
         if (!h->split) h->s2_ok = false;
         // A chain is "light" when its last sweep met few live clusters per step.  With the settled-chain kernel: as many as that kernel's
         // LDS id tables hold (it evaluates any number in place -- HL's busiest chains, 40-90 ids per step, run 20 % faster there than
         // in the general kernel -- but a K = 1 chain that never resamples keeps thousands of private clusters, and those steps belong to
         // the general kernel's hash tables: cfg2 with every chain light took 3.4 s per sweep instead of 0.8).  Without it: 40.
-        h->light_ids = env_int("PMDI_LIGHT_IDS", h->s2_ok ? h->s2.idcap : 40);
-        if (h->s2_ok && env_int("PMDI_SETTLED", 1) == 2) h->light_ids = 1LL << 40;      // (tests: every chain starts every sweep on the settled-chain kernel)
-        h->sticky = env_int("PMDI_STICKY", 3);
-        h->s2_continue = env_int("PMDI_CONTINUE", 1) != 0;
+        h->light_ids = knob(tn.light_ids, h->s2_ok ? h->s2.idcap : 40);
+        if (h->s2_ok && knob(tn.settled, 1) == 2) h->light_ids = 1LL << 40;      // (tests: every chain starts every sweep on the settled-chain kernel)
+        h->sticky = knob(tn.sticky, 3);
+        h->s2_continue = knob(tn.continue_inplace, 1) != 0;
         if (h->split) {
             if (configure(256, h->l_terms_cap, h->l_pid_lds, h->l_pp_lds, h->l_col_lds)) h->split = false;
         }
@@ -681,14 +708,13 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 return bail(fail(PMDI_E_DEVICE, "stream/event creation failed"));
             // (with the settled-chain kernel only the few chains it gave back lately are heavy at all: no CU-each launch for them --
             // HL 1 160 it/s without against 1 146 with it -- and so no start gate either, which a profiler would switch off)
-            h->very_heavy = (h->T == 512 && h->two_per_cu) ? env_int("PMDI_VERY_HEAVY", h->s2_ok ? 0 : 128) : 0;
+            h->very_heavy = (h->T == 512 && h->two_per_cu) ? knob(tn.very_heavy, h->s2_ok ? 0 : 128) : 0;
             int can_wait = 0;
             (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, cfg->device);
             // (not under a profiler that collects counters: rocprofv3 --pmc runs the kernels of all queues one at a time, and a launch
             // that waits for another launch's workgroups then never starts -- observed as a hang of the FETCH_SIZE pass)
-            auto env_has = [](const char *name, const char *what) { const char *v = getenv(name); return v && strstr(v, what) != nullptr; };
-            const bool profiled = env_has("LD_PRELOAD", "rocprof") || env_has("ROCP_TOOL_LIBRARIES", "rocprof") || env_has("HSA_TOOLS_LIB", "rocprof");
-            if (h->very_heavy > 0 && can_wait && !profiled && env_int("PMDI_START_GATE", 1) != 0) {
+            const bool profiled = tn.profiled > 0;
+            if (h->very_heavy > 0 && can_wait && !profiled && knob(tn.start_gate, 1) != 0) {
                 void *sig = nullptr;
                 if (hipExtMallocWithFlags(&sig, 8, hipMallocSignalMemory) == hipSuccess) {
                     h->start_sig = (unsigned *)sig; h->owned.push_back(sig);
@@ -734,7 +760,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         ((rc = h->d_anclog.ensure((size_t)C * (size_t)n * P * 4)) || (rc = h->d_evpos.ensure((size_t)C * 2 * (size_t)n * 4))))
         return bail(rc);
     // first sweep: every chain is heavy (PMDI_SETTLED=2: every chain starts on the settled-chain kernel -- tests of its hand-back path)
-    if (hipMemset(h->d_group.p, (h->s2_ok && getenv("PMDI_SETTLED") && atoi(getenv("PMDI_SETTLED")) == 2) ? 0 : 1, (size_t)C) != hipSuccess)
+    if (hipMemset(h->d_group.p, (h->s2_ok && tn.settled == 2) ? 0 : 1, (size_t)C) != hipSuccess)
         return bail(fail(PMDI_E_DEVICE, "hipMemset failed"));
 
     // null-cluster marginal (src/pmdi.jl:120-128): all rows in one cluster, all features on

@@ -23,7 +23,7 @@ using DelimitedFiles, Distributions, Printf, Random
 using NonUniformRandomVariateGeneration: sampleCategorical
 
 const LIB = get(ENV, "PMDI_HIP_LIB", joinpath(@__DIR__, "..", "libpmdi_hip.so"))
-const PMDI_ABI_VERSION = Int32(1)
+const PMDI_ABI_VERSION = Int32(2)
 
 # mirrors of the C structs in include/pmdi_hip.h
 struct CDataset
@@ -48,6 +48,7 @@ struct CConfig
     pool_cap::Int64
     block_threads::Int32
     reserved::Int32
+    tuning::Ptr{Cvoid}      # const pmdi_tuning * (kernel-selection knobs); C_NULL = all automatic
 end
 
 struct CSweepStats
@@ -107,7 +108,7 @@ function pmdi(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float64, ite
                        kinds[k] == 0 ? pointer(mats[k]) : Ptr{Float64}(C_NULL),
                        kinds[k] == 0 ? Ptr{Int64}(C_NULL) : pointer(mats[k])) for k in 1:K]
         cfg = Ref(CConfig(PMDI_ABI_VERSION, Int32(device), Int32(K), Int32(N), Int32(particles), Int32(1),
-                          Int64(n_obs), seed, Int32(0), Int32(0), Int64(0), Int32(0), Int32(0)))
+                          Int64(n_obs), seed, Int32(0), Int32(0), Int64(0), Int32(0), Int32(0), C_NULL))
         check(ccall((:pmdi_create, LIB), Cint, (Ref{CConfig}, Ptr{CDataset}, Ref{Ptr{Cvoid}}), cfg, ds, handle))
     end
     h = handle[]
@@ -238,7 +239,7 @@ function pmdi_device(dataFiles, dataTypes, N::Int64, particles::Int64, ρ::Float
                        kinds[k] == 0 ? pointer(mats[k]) : Ptr{Float64}(C_NULL),
                        kinds[k] == 0 ? Ptr{Int64}(C_NULL) : pointer(mats[k])) for k in 1:K]
         cfg = Ref(CConfig(PMDI_ABI_VERSION, Int32(device), Int32(K), Int32(N), Int32(particles), Int32(1),
-                          Int64(n_obs), seed, Int32(0), Int32(q2_mode), Int64(0), Int32(0), Int32(0)))
+                          Int64(n_obs), seed, Int32(0), Int32(q2_mode), Int64(0), Int32(0), Int32(0), C_NULL))
         check(ccall((:pmdi_create, LIB), Cint, (Ref{CConfig}, Ptr{CDataset}, Ref{Ptr{Cvoid}}), cfg, ds, handle))
     end
     h = handle[]

@@ -22,7 +22,23 @@ def test_header_symbols_exported(pkg):
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/pmdi_hip.h but not exported"
     assert set(pkg.EXPORTS) == set(names)
-    assert lib.pmdi_abi_version() == pkg.ABI_VERSION == 1
+    assert lib.pmdi_abi_version() == pkg.ABI_VERSION == 2
+
+
+def test_the_library_reads_the_environment_only_on_request():
+    """no process-global state behind the ABI.  The kernel-selection knobs travel in pmdi_config.tuning; getenv appears in
+    the product's sources in exactly one function, pmdi_tuning_from_env, which a caller has to call itself."""
+    csrc = os.path.join(ROOT, "particlemdi.jl_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            txt = open(os.path.join(csrc, f), errors="ignore").read()
+            hits += [(f, i + 1) for i, line in enumerate(txt.split("\n")) if re.search(r"\bgetenv\s*\(", line)]
+    assert hits and all(f == "pmdi_api.cpp" for f, _ in hits), hits
+    api = open(os.path.join(csrc, "pmdi_api.cpp")).read()
+    body = api[api.index("void pmdi_tuning_from_env("):]
+    body = body[:body.index("\n}\n") + 3]
+    assert api.count("getenv") == body.count("getenv"), "getenv outside pmdi_tuning_from_env"
 
 
 def test_code_object_is_gfx950(pkg):
