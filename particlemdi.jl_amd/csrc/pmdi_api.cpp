@@ -662,7 +662,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 // chain over to the general kernel: with N labels a single ambiguous observation fans one class out into up to N)
                 int cls = knob(tn.s2_cls, 32);
                 if (cls < 16) cls = 16;
-                if (cls > 32) cls = 32;
+                if (cls > pmdi_sweep2_max_classes(K, P)) cls = pmdi_sweep2_max_classes(K, P);
                 cls &= ~3;
                 pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, &h->s2);
                 while ((size_t)h->s2.total > budget && cls > 16) { cls -= 4; pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, &h->s2); }

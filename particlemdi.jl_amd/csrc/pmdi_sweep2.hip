@@ -64,6 +64,14 @@ void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, in
     pmdi_s2::make_layout(K, N, P, Dmax, cols_l, idcap, cls, *L);
 }
 
+// particle classes per dataset the class slots of that shape's lanes can name (the LDS tables may hold fewer: S2Layout::cls)
+int pmdi_sweep2_max_classes(int K, int P)
+{
+    int nw = 0;
+    if (!kernel_for(K, P, &nw)) return 0;
+    return pmdi_s2::class_slots_max(K, P / (64 * nw), nw);
+}
+
 int pmdi_sweep2_threads(int K, int P)
 {
     int nw = 0;

@@ -202,16 +202,23 @@ typedef unsigned short u16;
 typedef unsigned char u8;
 
 constexpr int NWMAX = 8;        // waves of a workgroup at most (the workgroup has NW of them: a template parameter of the sweep)
-constexpr int NS = 8;           // cluster cache slots per dataset (registers of the owner wave)
+#ifndef PM2_NS
+#define PM2_NS 8
+#endif
+constexpr int NS = PM2_NS;      // cluster cache slots per dataset (registers of the owner wave)
 constexpr int XR = 4;           // uncached clusters evaluated per round (their two term rows each borrow the cached clusters' tb rows)
 #ifndef PM2_XCAP
 #define PM2_XCAP 24
 #endif
 constexpr int XCAP = PM2_XCAP;  // uncached reachable clusters whose list entry and log-predictive live in LDS (the rest: arena)
-constexpr int NR = NS;          // term rows per dataset
+constexpr int NR = (NS > 2 * XR) ? NS : 2 * XR;      // term rows per dataset (a round of uncached clusters needs two each)
 constexpr int CLSMAX = 32;      // particle classes per dataset the class slots of a lane can name; how many of them a handle's LDS
                                 // tables hold (16 .. 32, Layout::cls) is the host's choice for the LDS budget.  A step with more: hand-over
-constexpr int CSB = 5;          // bits of a class slot in the per-lane register word
+// bits of a class slot in a lane's register word(s): four where all K * PPL slots of the lane then share ONE 64-bit word (K = 4
+// datasets x 4 particles per lane on four waves, the headline shape: its LDS budget holds 16 classes per dataset anyway, and the
+// two-word form cost that kernel 5 % per step), else five -- one word per dataset
+PM2_HD constexpr int class_slot_bits(int K, int PPL, int NW) { return (K == 4 && PPL == 4 && NW == 4) ? 4 : 5; }
+PM2_HD constexpr int class_slots_max(int K, int PPL, int NW) { return 1 << class_slot_bits(K, PPL, NW); }
 constexpr int KCAPMAX = 256;    // (class, label) keys a step may touch at most (the key lists of the bookkeeping phase; Layout::kcap)
 constexpr int RI_CLSMIN = 64, RI_NEWSLOT = 96, RI_CLSVAL = 128;     // resampling: per-class scratch (CLSMAX ints each), int offsets into the reduction area
 constexpr int RI_WCNT = 160;                                         // ... and per-wave counts of the block scans (NWMAX ints)
@@ -398,12 +405,16 @@ struct Sweep2 {
     RegArr<double, PPL> lw;
     static constexpr int NCP = (PPL + 1) / 2;
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
-    // class slot of the lane's particles, one word per dataset (32 bits while they fit), CSB bits each: bit offset CSB * u
+    // class slot of the lane's particles, CSB bits each: in ONE 64-bit word (bit offset CSB * (k * PPL + u)) when they all fit,
+    // else one word per dataset (32 bits while that fits; bit offset CSB * u)
+    static constexpr int CSB = class_slot_bits(K, PPL, NW);
+    static constexpr bool ONEWORD = CSB * K * PPL <= 64;
+    static constexpr int NCSW = ONEWORD ? 1 : K;
     template <bool Wide, class Dummy = void> struct CslWord { typedef unsigned type; };
     template <class Dummy> struct CslWord<true, Dummy> { typedef u64 type; };
-    typedef typename CslWord<(CSB * PPL > 32)>::type csl_t;
-    RegArr<csl_t, K> cslp;
-    static_assert(CSB * PPL <= 64 && (1 << CSB) >= CLSMAX, "class slots of a lane's particles of one dataset must fit one 64-bit word");
+    typedef typename CslWord<(ONEWORD || CSB * PPL > 32)>::type csl_t;
+    RegArr<csl_t, NCSW> cslp;
+    static_assert(CSB * PPL <= 64, "class slots of a lane's particles of one dataset must fit one 64-bit word");
     RegArr<double, NS> c_mu, c_lam;     // owner wave: the cluster cache of its dataset (mu, lambda per feature; Sigma, beta stay in the pool), lane = feature
 #ifdef PM2_DETAIL_TIMERS
     long long phd_last;
@@ -454,8 +465,17 @@ struct Sweep2 {
     {
         lw.set(u, x);
     }
-    PM2_DEV int csl_get(int k, int u) const { return (int)((cslp[k] >> (CSB * u)) & (csl_t)((1 << CSB) - 1)); }
-    PM2_DEV void csl_put(int k, int u, int r) { const int sh = CSB * u; cslp.set(k, (csl_t)((cslp[k] & ~((csl_t)((1 << CSB) - 1) << sh)) | ((csl_t)r << sh))); }
+    PM2_DEV int csl_get(int k, int u) const
+    {
+        if (ONEWORD) return (int)((cslp[0] >> (CSB * (k * PPL + u))) & (csl_t)((1 << CSB) - 1));
+        return (int)((cslp[k] >> (CSB * u)) & (csl_t)((1 << CSB) - 1));
+    }
+    PM2_DEV void csl_put(int k, int u, int r)
+    {
+        const int sh = ONEWORD ? CSB * (k * PPL + u) : CSB * u;
+        const int w = ONEWORD ? 0 : k;
+        cslp.set(w, (csl_t)((cslp[w] & ~((csl_t)((1 << CSB) - 1) << sh)) | ((csl_t)r << sh)));
+    }
     PM2_DEV DV view(int k) const
     {
         DV v;
@@ -1901,7 +1921,7 @@ struct Sweep2 {
 #pragma unroll
             for (int j = 0; j < NCP; ++j) colp.set(k * NCP + j, 0u);
 #pragma unroll
-        for (int k = 0; k < K; ++k) cslp.set(k, (csl_t)0);
+        for (int k = 0; k < NCSW; ++k) cslp.set(k, (csl_t)0);
 #pragma unroll
         for (int s = 0; s < NS; ++s) { c_mu.set(s, 0.0); c_lam.set(s, 1.0); }
         PM2_BARRIER();

@@ -90,6 +90,11 @@ void *emu_create(int K, long long n, int N, int P, const int *D, const double *c
     if (K < 1 || K > pmdi_s2::KMAX2 || (P != 256 && P != 512 && P != 1024 && P != 2048) || N > 64) return nullptr;
     Emu *e = new Emu();
     e->K = K; e->N = N; e->P = P; e->n = n; e->cap = (long long)N * P + 1; e->seed = seed; e->q1 = q1;
+    {
+        const int nw = P > 1024 ? 8 : 4;
+        const int mx = pmdi_s2::class_slots_max(K, P / (64 * nw), nw);
+        if (cls > mx) cls = mx;
+    }
     e->cols_l = cols_l; e->idcap = idcap; e->cls = cls;
     memset(e->ds, 0, sizeof(e->ds));
     e->x.resize(K); e->gtab.resize(K); e->arena.resize(K); e->lhtab.resize(K); e->lgtab.resize(K); e->xi.resize(K); e->maxcol.resize(K);
