@@ -51,7 +51,17 @@ DESCR = {
 # chains per GPU (one workgroup each) and burn-in iterations per workload.  HL: 2 048 chains since round 3 (227 GB of the 288 GB: the
 # arena of a chain is sized for N * P + 1 cluster ids) -- 512 workgroup slots, so four rounds of chains instead of two pack under the
 # slowest chain: 1 146 it/s against 1 001-1 009 with 1 024 chains (profiles/README.md r03 keeps both operating points)
-DEFAULTS = {"HL": (2048, 20), "cfg2": (2048, 30), "cfg3": (1024, 12), "cfg4": (256, 6), "cfg5": (16, 3)}
+DEFAULTS = {"HL": (3072, 20), "cfg2": (2048, 30), "cfg3": (2048, 12), "cfg4": (1024, 6), "cfg5": (80, 3)}
+# Cluster ids per dataset a chain's pool holds, as a fraction of the reference's N*P+1 (src/pmdi.jl:140).  Measured (scripts/pool_need.py,
+# profiles/r04/pool_need.txt): the largest id a chain touches is 0.18-0.33 of N*P+1 in its FIRST sweep from the random start and below
+# 0.05-0.19 afterwards, so the statistics pool -- 60-85 % of a chain's memory -- is mostly never touched.  A smaller pool is what lets a GPU
+# hold 2-4x more chains than workgroup slots (better packing under the slowest chain).  Margin >= 1.5x over the measured first-sweep
+# peak; a chain that needs more reports PMDI_E_POOL and the bench starts over with the full pool (FULLPOOL_CHAINS).
+POOL_FRAC = {"HL": 0.4, "cfg2": 1.0, "cfg3": 1.0, "cfg4": 0.3, "cfg5": 1.0}
+FULLPOOL_CHAINS = {"HL": 2048, "cfg2": 2048, "cfg3": 2048, "cfg4": 512, "cfg5": 80}
+# (round 4: HL 3 072 chains (six rounds on the 512 workgroup slots: 1 218 it/s against 1 180 with 2 048), cfg3 2 048, cfg4 1 024 on 256
+# slots -- a sweep lasts as long as its slowest chain once the rest packs under it.  cfg5: 80 chains = 240 workgroups of the
+# K-workgroups-per-chain form, the only form whose LDS tables hold P = 4 096, N = 50: one per CU; round 3 ran 16)
 
 
 def algorithmic_bytes(w, P, n, n1, work, stats, layout="column"):
@@ -116,6 +126,43 @@ def oracle_chain(w, state, n_iter, seed, progress=False):
 
 
 KERNEL_NAMES = {0: "general", 1: "settled-chain", 2: "general after a hand-back"}
+
+
+def one_chain_alone(pkg, w, g, chain, seed, device, fsel, torch):
+    """ONE chain alone on the GPU -- the reference's use (README.md:31-46 runs one chain) -- continuing a settled chain of the run:
+    sweep-only iterations/s in every form a single-chain handle can take: the settled-chain kernel (one workgroup), the general
+    kernel in one workgroup, and for K > 1 the general kernel with K cooperating workgroups (what pmdi_create picks by itself for a
+    small batch is reported as `default_form`)."""
+    K = w["K"]
+    forms = {"settled_chain_kernel": {"ksplit": 0, "settled": 2, "sticky": 0}, "general_kernel_one_workgroup": {"ksplit": 0, "settled": 0}}
+    if K > 1:
+        forms["general_kernel_K_workgroups"] = {"ksplit": 1}
+    forms["default_form"] = {}
+    st = g.get(chain)
+    stream = torch.cuda.current_stream(torch.device("cuda", device))
+    out = {}
+    for name, tun in forms.items():
+        sw1 = pkg.Sweeper(w["data"], w["kinds"], w["N"], w["P"], n_chains=1, seed=seed + (2 << 20) + chain, device=device, tuning=tun)
+        g1 = pkg.Gibbs(sw1, rho=w["rho"], feature_select=fsel)
+        g1.set(0, M=st["M"], gamma=st["gamma"], gamma0=st["gamma0"], Phi=st["Phi"], v=st["v"], Z=st["Z"], s=st["s"], order=st["order"], flags=st["flags"])
+        ms = []
+        for it in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g1.step(pkg.STEP_BEGIN, stream.cuda_stream); g1.step(pkg.STEP_HYPERS, stream.cuda_stream)
+            e0.record(stream); g1.step(pkg.STEP_SWEEP, stream.cuda_stream); e1.record(stream)
+            if fsel:
+                g1.step(pkg.STEP_FEATSEL, stream.cuda_stream)
+            g1.step(pkg.STEP_ALIGN, stream.cuda_stream)
+            torch.cuda.synchronize()
+            if it >= 2:
+                ms.append(e0.elapsed_time(e1))
+        g1.results()
+        out[name] = {"sweep_only_iters_per_sec": 1e3 / float(np.mean(ms)), "sweep_ms": float(np.mean(ms)),
+                     "finished_by": KERNEL_NAMES.get(int(sw1.swept_by()[0]), "?"), "workgroups": (K if sw1.split else 1),
+                     "settled_chain_kernel_enabled": bool(sw1.settled)}
+        g1.close(); sw1.close()
+    out["note"] = "one settled chain of the run (median cost) alone on the GPU, 4 timed sweeps after 2; the CPU figure beside it is cpu_baseline.one_core_alone_iters_per_sec"
+    return out
 
 
 def parity_check(pkg, w, g, sw, chains, seed, fsel):
@@ -226,6 +273,9 @@ def main():
     ap.add_argument("--chains", type=int, default=0, help="independent chains per GPU (one workgroup each); 0 = the workload's default")
     ap.add_argument("--burnin", type=int, default=-1, help="iterations from the random start before --warmup; -1 = the workload's default")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink n of the workload (debug only)")
+    ap.add_argument("--pool-frac", type=float, default=0.0, help="cluster ids per dataset a chain's pool holds, as a fraction of the reference's N*P+1 "
+                    "(src/pmdi.jl:140); 0 = the workload's default (POOL_FRAC).  A sweep that needs more stops with PMDI_E_POOL: the bench then starts "
+                    "over with the full pool and the chain count that fits it")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of one timed-state chain (outside the timed region)")
@@ -261,8 +311,33 @@ def main():
     burnin = args.burnin if args.burnin >= 0 else DEFAULTS[args.workload][1]
     # chain c of rank r draws from Philox key base + r * 2^32 + c: no two chains of a job share a stream
     seed = 1000 + (rank << 32)
-    sw = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=C, seed=seed, device=local_rank, block_threads=args.block)
-    g = pkg.Gibbs(sw, rho=w["rho"], feature_select=(args.workload == "cfg5"))
+    chains_requested = C
+    state = {}
+
+    def build_chains(C_, pool_frac):
+        """The handle (all chains of this rank) and its device-resident Gibbs state; fewer chains if the device's free memory says so."""
+        pool_cap = 0 if pool_frac >= 1.0 else max(N + 2, int(pool_frac * (N * P + 1)))
+        while True:
+            try:
+                sw_ = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=C_, seed=seed, device=local_rank, block_threads=args.block, pool_cap=pool_cap)
+                break
+            except pkg.PmdiError as e:
+                if e.code != -3 or C_ <= 8:          # PMDI_E_MEMORY
+                    raise
+                C_ = max(8, (C_ * 3 // 4) // 8 * 8)
+                print(f"[bench] rank {rank}: not enough device memory for {chains_requested} chains; trying {C_}", file=sys.stderr, flush=True)
+        if dist is not None:                         # every rank runs the same number of chains
+            tC = torch.tensor([C_], dtype=torch.int64, device=dev)
+            dist.all_reduce(tC, op=dist.ReduceOp.MIN)
+            if int(tC.item()) != C_:
+                C_ = int(tC.item())
+                sw_.close()
+                sw_ = pkg.Sweeper(w["data"], w["kinds"], N, P, n_chains=C_, seed=seed, device=local_rank, block_threads=args.block, pool_cap=pool_cap)
+        state["sw"], state["g"], state["C"] = sw_, pkg.Gibbs(sw_, rho=w["rho"], feature_select=(args.workload == "cfg5")), C_
+
+    pool_frac = args.pool_frac if args.pool_frac > 0 else POOL_FRAC.get(args.workload, 1.0)
+    build_chains(C, pool_frac)
+    sw, g, C = state["sw"], state["g"], state["C"]
     n1 = g.n1
     n_s = n - n1 + 1
     stream = torch.cuda.current_stream(dev)
@@ -292,6 +367,28 @@ def main():
     barrier()
     tb = time.perf_counter()
     for b in range(burnin):
+        if b == 1 and pool_frac < 1.0:
+            # the first sweep from the random start is the one that needs the most cluster ids: did every chain's pool hold them?
+            torch.cuda.synchronize()
+            bad = 0
+            try:
+                g.results()
+            except pkg.PmdiError as e:
+                if e.code != -4:
+                    raise
+                bad = 1
+            if dist is not None:
+                tb_ = torch.tensor([bad], dtype=torch.int64, device=dev)
+                dist.all_reduce(tb_, op=dist.ReduceOp.MAX)
+                bad = int(tb_.item())
+            if bad:
+                print(f"[bench] a chain's first sweep needed more than {pool_frac:.2f} x (N*P+1) cluster ids: starting over with the full pool", file=sys.stderr, flush=True)
+                g.close(); sw.close()
+                pool_frac = 1.0
+                build_chains(min(chains_requested, FULLPOOL_CHAINS.get(args.workload, chains_requested)), 1.0)
+                sw, g, C = state["sw"], state["g"], state["C"]
+                iteration([])
+                tb = time.perf_counter() - 0.0
         ev = []
         iteration(ev)
         if args.verbose and rank == 0:
@@ -366,7 +463,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": DESCR[args.workload] if args.scale == 1.0 else f"{args.workload} scaled n={n}",
-                       "chains_per_gpu": C, "burnin_iterations": burnin,
+                       "chains_per_gpu": C, "chains_requested": chains_requested, "burnin_iterations": burnin,
+                       "pool_ids_per_dataset": int(sw.cap), "pool_frac_of_reference": float(sw.cap) / float(N * P + 1),
                        "block_threads": sw.block_threads, "lds_bytes_per_workgroup": sw.lds_bytes,
                        "workgroups_per_chain": (K if sw.split else 1),
                        "swept_obs_per_iter": n_s, "parallelism": f"chains x{world}",
@@ -451,6 +549,8 @@ def main():
                                "note": "K cooperating workgroups per chain (one per dataset), one sc1 hand-off per swept observation; "
                                        "same settled chains as the throughput run, 3 timed iterations after 2"}
         g2.close(); sw2.close()
+    if rank == 0 and not args.no_latency_form:
+        out["one_chain_alone"] = one_chain_alone(pkg, w, g, int(np.argsort(costs)[C // 2]), seed, local_rank, args.workload == "cfg5", torch)
     if rank == 0:
         print(f"[bench] GPU part done: {out['value']:.1f} iters/s", file=sys.stderr, flush=True)
         if not args.no_cpu:
