@@ -142,7 +142,11 @@ def one_chain_alone(pkg, w, g, chain, seed, device, fsel, torch):
     stream = torch.cuda.current_stream(torch.device("cuda", device))
     out = {}
     for name, tun in forms.items():
-        sw1 = pkg.Sweeper(w["data"], w["kinds"], w["N"], w["P"], n_chains=1, seed=seed + (2 << 20) + chain, device=device, tuning=tun)
+        try:
+            sw1 = pkg.Sweeper(w["data"], w["kinds"], w["N"], w["P"], n_chains=1, seed=seed + (2 << 20) + chain, device=device, tuning=tun)
+        except pkg.PmdiError as e:           # (a form this configuration cannot take: e.g. P = 4 096, N = 50 in one workgroup's LDS)
+            out[name] = {"not_available": str(e)}
+            continue
         g1 = pkg.Gibbs(sw1, rho=w["rho"], feature_select=fsel)
         g1.set(0, M=st["M"], gamma=st["gamma"], gamma0=st["gamma0"], Phi=st["Phi"], v=st["v"], Z=st["Z"], s=st["s"], order=st["order"], flags=st["flags"])
         ms = []
