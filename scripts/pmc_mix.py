@@ -13,7 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 name, chains, out = sys.argv[1], sys.argv[2], sys.argv[3]
-sys.path.insert(0, os.path.join(ROOT, "particlemdi.jl_amd"))
+sys.path.insert(0, ROOT)
 A = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
 B = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
 prof = os.path.join(ROOT, "gpurun_out", "prof")
@@ -37,7 +37,9 @@ for tag, ctrs in (("A", A), ("B", B)):
             acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     raw[tag] = acc
     kname = rows[-1]["Kernel_Name"]
-import workloads  # noqa: E402
+import __graft_entry__ as G  # noqa: E402
+G.load_package()
+from particlemdi_jl_amd import workloads  # noqa: E402
 w = workloads.make(name)
 n_s = w["n"] - int(w["rho"] * w["n"]) + 1
 waves = raw["A"]["SQ_WAVES"]
