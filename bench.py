@@ -458,6 +458,18 @@ def main():
             if traffic is None:           # the bytes of a sweep do not depend on how many sweeps were timed: same workload, chains, burn-in
                 pre = f"{args.workload}|chains={C}|burnin={burnin}|"
                 traffic = next((v.get("hbm_bytes_per_sweep") for k_, v in tj.items() if k_.startswith(pre) and k_.endswith(f"|scale={args.scale}")), None)
+        # second ceiling: how busy the issue slots of the dominant kernel are (PMC, profiles/r04/pmc_instruction_mix.json): HBM is at a few
+        # per cent of its peak here and says little about this kernel; its waves wait on dependent LDS / L2 round trips, logs and barriers
+        issue = None
+        mpath = os.path.join(ROOT, "profiles", "r04", "pmc_instruction_mix.json")
+        if args.workload == "HL" and os.path.exists(mpath):
+            mj = json.load(open(mpath))
+            fr = mj["fractions_of_wave_cycles"]
+            issue = {"issue_slots_busy_frac": fr["SQ_ACTIVE_INST_ANY"], "valu_frac": fr["SQ_ACTIVE_INST_VALU"], "scalar_frac": fr["SQ_ACTIVE_INST_SCA"],
+                     "lds_frac": fr["SQ_ACTIVE_INST_LDS"], "wait_frac": fr["SQ_WAIT_ANY"], "waves_per_simd": 2,
+                     "instructions_per_wave_and_observation": mj["instructions_per_wave_and_observation"],
+                     "source": "profiles/r04/pmc_instruction_mix.json (rocprofv3 --pmc, two passes, the settled-chain kernel's dispatch of a 1 024-chain sweep): "
+                               "fractions of SQ_WAVE_CYCLES"}
         out = {
             "metric": "Gibbs iters/sec (and obs·particles/sec) at 1/2/4/8 GPUs vs CPU ref",
             "value": total_iters / dt,
@@ -499,6 +511,7 @@ def main():
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_over_algorithmic": (traffic / alg) if traffic else None,
                          "algorithmic_bytes_per_sweep": alg, "dense_model_ratio": dense / alg,
+                         "issue_rate": issue,
                          "per_particle_table_model": {"algorithmic_bytes_per_sweep": alg_pp, "frac": alg_pp / (kernel_ms * 1e-3) / HBM_PEAK,
                                                       "note": "the same sweep priced with the byte model of the builds that kept particle[:, :, k] "
                                                               "as an N x P table per particle (rounds 1-2 before the column table): what frac "
