@@ -51,14 +51,14 @@ DESCR = {
 # chains per GPU (one workgroup each) and burn-in iterations per workload.  HL: 2 048 chains since round 3 (227 GB of the 288 GB: the
 # arena of a chain is sized for N * P + 1 cluster ids) -- 512 workgroup slots, so four rounds of chains instead of two pack under the
 # slowest chain: 1 146 it/s against 1 001-1 009 with 1 024 chains (profiles/README.md r03 keeps both operating points)
-DEFAULTS = {"HL": (3072, 20), "cfg2": (2048, 30), "cfg3": (2048, 12), "cfg4": (1024, 6), "cfg5": (80, 3)}
+DEFAULTS = {"HL": (3072, 20), "cfg2": (2048, 30), "cfg3": (3072, 12), "cfg4": (1024, 6), "cfg5": (80, 3)}
 # Cluster ids per dataset a chain's pool holds, as a fraction of the reference's N*P+1 (src/pmdi.jl:140).  Measured (scripts/pool_need.py,
 # profiles/r04/pool_need.txt): the largest id a chain touches is 0.18-0.33 of N*P+1 in its FIRST sweep from the random start and below
 # 0.05-0.19 afterwards, so the statistics pool -- 60-85 % of a chain's memory -- is mostly never touched.  A smaller pool is what lets a GPU
 # hold 2-4x more chains than workgroup slots (better packing under the slowest chain).  Margin >= 1.5x over the measured first-sweep
 # peak; a chain that needs more reports PMDI_E_POOL and the bench starts over with the full pool (FULLPOOL_CHAINS).
 POOL_FRAC = {"HL": 0.4, "cfg2": 1.0, "cfg3": 1.0, "cfg4": 0.3, "cfg5": 1.0}
-FULLPOOL_CHAINS = {"HL": 2048, "cfg2": 2048, "cfg3": 2048, "cfg4": 512, "cfg5": 80}
+FULLPOOL_CHAINS = {"HL": 2048, "cfg2": 2048, "cfg3": 3072, "cfg4": 512, "cfg5": 80}
 # (round 4: HL 3 072 chains (six rounds on the 512 workgroup slots: 1 218 it/s against 1 180 with 2 048), cfg3 2 048, cfg4 1 024 on 256
 # slots -- a sweep lasts as long as its slowest chain once the rest packs under it.  cfg5: 80 chains = 240 workgroups of the
 # K-workgroups-per-chain form, the only form whose LDS tables hold P = 4 096, N = 50: one per CU; round 3 ran 16)
@@ -292,7 +292,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    saved_stdout = None
     if world > 1 or os.environ.get("PMDI_BENCH_FORCE_DIST"):     # the env var rehearses the RCCL path on one GPU
+        # RCCL prints a version banner on stdout when a communicator is created: stdout carries ONE JSON line, so everything
+        # up to that line goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
@@ -576,7 +582,10 @@ def main():
             states = [g.get(c) for c in pick]
             out["cpu_baseline"] = cpu_baseline(w, args.scale, states, args.cpu_seconds)
             out["gpu_over_all_host_cores"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
     g.close(); sw.close()
 
 

@@ -448,6 +448,69 @@ def test_settled_chain_kernel_mixed_types_equal_oracle(pkg, O, monkeypatch, kind
     sw.close()
 
 
+@pytest.mark.parametrize("kinds,P,N,flags", [
+    (("gaussian", "gaussian", "gaussian", "gaussian"), 1024, 40, False),          # 4-bit class slots (the headline shape): 16 classes
+    (("gaussian", "categorical"), 512, 40, True),                                   # 5-bit slots, tables squeezed to 16 classes
+    (("categorical", "negbinom", "gaussian"), 256, 30, False),
+    (("gaussian", "gaussian", "categorical", "negbinom"), 2048, 50, False),       # 512-thread workgroups
+    (("gaussian",), 512, 40, False),
+], ids=["K4-P1024", "gau+cat-flags", "cat+nb+gau", "cfg4-shape", "K1"])
+def test_hand_over_mid_sweep_equals_oracle(pkg, O, kinds, P, N, flags):
+    """The settled-chain kernel hands a chain over to the general kernel's code IN PLACE at the observation whose step does not fit its
+    tables (here: more than 16 particle classes -- the class capacity is squeezed to 16 and the prior leaves mass on many empty
+    labels, so hand-overs happen at assorted positions of the sweep, in one or several datasets of the same observation, and again
+    in later iterations after the chain has returned to the settled-chain kernel).  Everything the reference defines is compared with
+    the oracle: per-observation trace, allocations, picked particle, log-weights, counters, work counters, the exported state."""
+    kinds = list(kinds)
+    K = len(kinds)
+    rng = np.random.default_rng(300 + K + P)
+    n = 260
+    data, z = _mixed_planted(rng, n, kinds)
+    n1 = n // 4
+    C = 4
+    fl = None
+    if flags:
+        fl = np.concatenate([(rng.random(d.shape[1]) < 0.7).astype(np.uint8) for d in data])
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=C, seed=903, tuning={"settled": 2, "sticky": 0, "ksplit": 0, "s2_cls": 16})
+    assert sw.settled
+    orcs = [O.Oracle(data, kinds, N, P, seed=903 + c) for c in range(C)]
+    recs = [o.debug_steps(n - n1 + 1) for o in orcs]
+    Dcum = np.cumsum([d.shape[1] for d in data])[:-1]
+    s = np.repeat(np.repeat((z + 1)[None, :, None], K, axis=2), C, axis=0)
+    idx = rng.random(s.shape) < 0.08
+    s[idx] = rng.integers(1, N + 1, size=int(idx.sum()))
+    seen = set()
+    for it in range(1, 5):
+        order = np.stack([rng.permutation(n) + 1 for _ in range(C)])
+        hyp = [random_hypers(rng, N, K) for _ in range(C)]
+        for h in hyp:
+            h[0][:3] += 0.6; h[0][:] = h[0] / h[0].sum(0)
+        rg = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]),
+                      None if fl is None else np.stack([fl] * C), trace=True)
+        wk = sw.work_counters()
+        kern = sw.swept_by()
+        for c in range(C):
+            ro = orcs[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1], flags=None if fl is None else np.split(fl, Dcum), trace=True)
+            bad = np.where(~np.isclose(rg["trace"][c], ro["trace"], rtol=1e-9, atol=1e-9).all(axis=1))[0]
+            assert bad.size == 0, f"chain {c} iteration {it} (kernel {kern[c]}): first diverging swept observation {bad[0]}: gpu={rg['trace'][c][bad[0]]} cpu={ro['trace'][bad[0]]}"
+            assert (rg["s"][c] == ro["s"]).all() and int(rg["p_star"][c]) == ro["p_star"]
+            assert np.allclose(rg["logweight"][c], ro["logweight"], rtol=1e-9, atol=1e-8)
+            for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
+                assert rg["stats"][c][key] == ro["stats"][key], key
+            up, mv = orcs[c].work()
+            assert (wk[c][:, 1] == up).all() and (wk[c][:, 3] == mv).all()
+            check_work_counters(wk[c], recs[c], ro["trace"], N, int(kern[c]))
+            eg, eo = sw.export_state(c), orcs[c].export()
+            assert (eg["particle"] == eo["particle"]).all() and (eg["max_id"] == eo["max_id"]).all()
+            t5_invariants(eg, N, P, K, n)
+            seen.add(int(kern[c]))
+            s[c] = ro["s"]
+    gb = sw.given_back()
+    print(f"{'+'.join(kinds)} P={P}: kernels that finished the chain-sweeps {sorted(seen)}; hand-overs {gb.tolist()} of {4 * C} chain-sweeps")
+    assert 2 in seen and gb[3] >= 2          # chains were handed over mid-sweep ...
+    sw.close()
+
+
 def test_settled_chain_kernel_hands_back_what_does_not_fit(pkg, O, monkeypatch):
     """From the random start of src/pmdi.jl:63-66 a chain has dozens of particle classes (more than the sixteen the settled-chain
     kernel holds per dataset): forced onto that kernel it is handed back at once and the general kernel sweeps it: results equal the
