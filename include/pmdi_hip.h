@@ -75,7 +75,8 @@ typedef struct {
     int32_t s2_cols, s2_idcap, s2_cls; /* PMDI_S2_COLS / _IDCAP / _CLS  columns, cluster ids, particle classes per dataset its LDS tables hold
                              *                     (automatic 64 / 128 / 32, shrunk by pmdi_create to the LDS budget) */
     int32_t ksplit;         /* PMDI_KSPLIT         K > 1: 0 one workgroup per chain (throughput form) / 1 K cooperating workgroups per chain
-                             *                     (latency form); automatic: split while n_chains * K workgroups are resident at once */
+                             *                     (latency form); automatic: split while n_chains * K workgroups are resident at once and the
+                             *                     handle cannot have the settled-chain kernel (whose single workgroup is the faster form) */
     int32_t requeue_ksplit; /* PMDI_REQUEUE_KSPLIT (continue_inplace = 0 only) 0: re-run given-back chains in one workgroup instead of K */
     int32_t split;          /* PMDI_SPLIT          0: one launch per sweep instead of the heaviest / heavy / light launches */
     int32_t heavy_threads;  /* PMDI_HEAVY_T        workgroup width of the heavy group (512 or 1024) */

@@ -573,7 +573,12 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         // (q2_mode = 1) always keeps the single-workgroup form: its ancestor log is per chain.
         const bool ks_ok = K > 1 && cfg->q2_mode == 0 && (long long)K * n < (1LL << 27);
         const int ks_env = tn.ksplit;
-        h->ksplit = (ks_ok && ks_env != 0) ? 1 : 0;      // tentative: the layout below is the split form's
+        // ... unless the handle can have the settled-chain kernel (round 4): ONE workgroup of it sweeps a settled chain faster than the K
+        // cooperating workgroups of the general kernel do (HL, one chain alone on the GPU: 3.18 against 2.98-3.00 iterations/s,
+        // bench.py `one_chain_alone`), on a quarter of the workgroup slots
+        const bool s2_possible = knob(tn.settled, 1) != 0 && K >= 2 && cfg->block_threads == 0 && cfg->q1_mode == 0 && cfg->q2_mode == 0 &&
+                                 pmdi_sweep2_supports(K, N, P, h->Dmax, cap);
+        h->ksplit = (ks_ok && ks_env != 0 && !(ks_env < 0 && s2_possible)) ? 1 : 0;      // tentative: the layout below is the split form's
         h->phase_on = tn.phase_timers > 0;
         // per workgroup width: LDS term buffer (at least P doubles for the resampling weights, the
         // per-wave CDF exchange areas, a few rows of 2*D+1) and which per-particle tables fit LDS

@@ -1,13 +1,15 @@
-// pmdi_sweep2_body.h -- the conditional-SMC sweep for SETTLED chains (round 3): the same sweep as pmdi_sweep.hip
+// pmdi_sweep2_body.h -- the conditional-SMC sweep for SETTLED chains (rounds 3-4): the same sweep as pmdi_sweep.hip
 // (src/pmdi.jl:165-171, 188-350, 373; src/misc.jl:15-59), re-designed around what a settled chain looks like (scripts/step_stats.py:
 // 1-2 particle classes, <= 8 clusters a class leader can reach, 6-40 distinct columns of particle[:, :, k], ids below ~200):
 //
-//   * one 256-thread workgroup per chain, PPL = P / 256 consecutive particles per lane, their state (log-weight, column index
-//     and class slot per dataset) in REGISTERS for the whole sweep;
-//   * the K datasets of an observation run CONCURRENTLY: wave k owns dataset k for everything per cluster (lanes = features):
-//     the clusters a class leader can reach are cached in that wave's registers (Sigma, beta, mu, lambda per feature) under a
-//     stable slot per cluster id, so a step evaluates one log per (cluster, feature) and reads no pool memory; ordered sums
-//     (calc_logprob's feature loop, bit-identical) by one lane per cluster from an LDS transposition; the class CDFs by shuffles;
+//   * one workgroup of NW waves per chain (256 threads for P <= 1024, 512 for P = 2048), PPL = P / (64 NW) consecutive particles per
+//     lane, their state (log-weight, column index and class slot per dataset) in REGISTERS for the whole sweep;
+//   * the K datasets of an observation run CONCURRENTLY: wave k owns dataset k for everything per cluster (lanes = features), whatever
+//     its cluster type -- Gaussian, Categorical, NegBinom (src/datatypes/*.jl): st_load / st_add_store / st_terms / ordered_sum.
+//     Gaussian: the clusters a class leader can reach are cached in that wave's registers (mu, lambda per feature) under a
+//     stable slot per cluster id, so a step evaluates one log per (cluster, feature) and reads no pool memory; integer types read
+//     their counts / sums from the pool and host-built log / lgamma tables; ordered sums (calc_logprob's feature loop, bit-identical)
+//     by one lane per cluster from an LDS transposition; the class CDFs by shuffles;
 //   * the draw, the census of the chosen clusters and the Phi / ESS work run on all lanes for all K datasets at once; every
 //     per-id / per-column / per-(class, label) table is DIRECT-INDEXED in LDS (ids and columns are small here); what exceeds
 //     the LDS capacities (columns >= cols_l, ids >= idcap) lives in the chain's arena with the same indexing (slower, rare);
@@ -16,11 +18,13 @@
 //     leaf scans, the exact u += 1/P sequence per lane, slot counts by direct comparison, the gather through LDS, columns and
 //     ids compacted per column / per id.
 //
-// A chain that does not fit (more particle classes than CLS in a step) stops with err = PMDI_S2_REQUEUE and is swept again, from
-// the start, by pmdi_sweep.hip in the same call.
+// A chain whose step does not fit the tables (more particle classes than the layout holds, cluster ids beyond 16 bits) is HANDED
+// OVER: the bookkeeping phase checks before it commits, hand_over() writes the chain's state where the general kernel keeps it, and
+// the same workgroup carries on with the general kernel's code from that observation (PM2_RESUME_GENERAL, defined by pmdi_sweep2.hip).
 //
-// Everything here is written against a small lane API (PM2_* macros) so that tests/emu/ can run the same source on the CPU in a
-// lock-step workgroup emulator (test infrastructure; the product build is hipcc for gfx950 only).
+// Everything here is written against a small lane API (PM2_* macros).  This header defines it for gfx950; a translation unit that
+// defines PM2_LANE_API_PROVIDED first brings its own -- tests/emu/ does, to run the same source on the CPU in a lock-step workgroup
+// emulator (test infrastructure; the product build is hipcc for gfx950 only and never sees it).
 // Compile with -ffp-contract=off.  Reference lines are file:line relative to /root/reference.
 #pragma once
 #include "pmdi_arith.h"
