@@ -424,10 +424,15 @@ def main():
     torch.cuda.synchronize()
     allgather_ms = None
     if comm is not None:
-        gathered = torch.empty((world,) + tuple(samples.shape), dtype=torch.uint8, device=dev)
+        # every retained sample of every rank reaches every rank (the PSM's input), a few iterations' worth at a time: the receive
+        # buffer is reused, so that 8 ranks x 20 iterations x 3 072 chains (19.7 GB per rank in one piece) fit beside the chains' arenas
+        chunk = max(1, min(args.steps, int(4e9 // max(1, world * per))))
+        gathered = torch.empty((world, chunk) + tuple(samples.shape[1:]), dtype=torch.uint8, device=dev)
         ag0, ag1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ag0.record(stream)
-        comm.allgather(samples.data_ptr(), gathered.data_ptr(), samples.numel(), sp)      # RCCL over xGMI: the PSM's input
+        for k0 in range(0, args.steps, chunk):
+            kn = min(chunk, args.steps - k0)
+            comm.allgather(samples.data_ptr() + k0 * per, gathered.data_ptr(), kn * per, sp)      # RCCL over xGMI
         ag1.record(stream)
         torch.cuda.synchronize()
         allgather_ms = float(ag0.elapsed_time(ag1))       # inside the timed region; reported on its own so that sampling and exchange separate
