@@ -83,6 +83,7 @@ struct S2Layout {
         minp, nidv, knew, itemj, clist, klist, kval, krep, bmc, bmf, cbm, kbm, xid, dsc;
     int Dp, cols_l, idcap, total;
     int cls, kcap;          // particle classes per dataset the tables hold (16 .. 32); touched (class, label) keys per step the key lists hold
+    int cdfl;               // class slots whose mutation-CDF rows live in LDS (the rest of the cls rows: the chain's arena)
 };
 
 struct SweepArgs {
@@ -208,7 +209,7 @@ hipError_t pmdi_launch_sweep(const SweepArgs &a, SweepArgs *d_args, int n_chains
 // workgroups of the sweep kernel build (T threads, the argument block's LDS layout) that one CU holds at once
 hipError_t pmdi_sweep_blocks_per_cu(const SweepArgs &a, int T, int *blocks);
 // the settled-chain kernel (pmdi_sweep2.hip)
-void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, S2Layout *L);
+void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, int cdfl, S2Layout *L);
 bool pmdi_sweep2_supports(int K, int N, int P, int Dmax, long long cap);
 int pmdi_sweep2_threads(int K, int P);
 int pmdi_sweep2_max_classes(int K, int P);  // particle classes per dataset the class slots of that shape can name (16 or 32)      // threads of the workgroup that sweeps a chain of P particles (0: no build for it)

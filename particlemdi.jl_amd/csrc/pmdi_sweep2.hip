@@ -59,9 +59,9 @@ const void *kernel_for(int K, int P, int *nw)
 
 }  // namespace
 
-void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, S2Layout *L)
+void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, int cdfl, S2Layout *L)
 {
-    pmdi_s2::make_layout(K, N, P, Dmax, cols_l, idcap, cls, *L);
+    pmdi_s2::make_layout(K, N, P, Dmax, cols_l, idcap, cls, cdfl, *L);
 }
 
 // particle classes per dataset the class slots of that shape's lanes can name (the LDS tables may hold fewer: S2Layout::cls)

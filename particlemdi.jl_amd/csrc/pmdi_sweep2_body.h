@@ -239,11 +239,12 @@ enum { SC_FAIL = 0, SC_RES, SC_PSTAR, SC_NLEAF, SC_NPROG, SC_JS, SC_TMP0, SC_TMP
 
 typedef S2Layout Layout;   // byte offsets into the workgroup's LDS: computed on the host (make_layout), read from the argument block
 
-PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, Layout &L)
+PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, int cdfl, Layout &L)
 {
     const int CLS = cls;                                                   // particle classes per dataset the tables hold
     const int kcap = (CLS * N < KCAPMAX) ? CLS * N : KCAPMAX;              // touched (class, label) keys per step the key lists hold
-    L.cls = cls; L.kcap = kcap;
+    if (cdfl > cls) cdfl = cls;                                            // class slots whose CDF rows live in LDS (the rest: the chain's arena)
+    L.cls = cls; L.kcap = kcap; L.cdfl = cdfl;
     int o = 0;
     auto take = [&](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };
     const int Dp = (Dmax + 1) & ~1;
@@ -261,7 +262,7 @@ PM2_HD void make_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, in
     // the tb rows are dead once the ordered sums are done: their first 1 KiB is the CDF stage's exchange area (and the prefix's label
     // table), the class CDF rows (alive until the particle phase ends) start right behind it
     L.tr_cdf = 128 * 8;
-    L.tr_stride = L.tr_cdf + CLS * (N + 2) * 8;
+    L.tr_stride = L.tr_cdf + cdfl * (N + 2) * 8;
     if (L.tr_stride < NR * Dp * 8) L.tr_stride = NR * Dp * 8;
     L.tr_stride = (L.tr_stride + 15) & ~15;
     // resampling scratch (aliases the transient rows): u table (P doubles; once dead: the per-dataset gather tables scol, mult,
@@ -316,7 +317,8 @@ struct Arena {   // the chain's arrays of one dataset in global memory (what exc
     PM2_DEV int *dl() const { return (int *)(b + d->o_dl); }
     PM2_DEV u8 *sstar() const { return (u8 *)(b + d->o_sstar); }
     PM2_DEV double *lpx() const { return (double *)(b + d->o_s2x); }                      // log-predictives of the uncached clusters beyond XCAP
-    PM2_DEV int *xidx() const { return (int *)(b + d->o_s2x) + 2 * CLSMAX * 64; }        // ... and their ids (at most CLSMAX * N <= CLSMAX * 64 entries each)
+    PM2_DEV int *xidx() const { return (int *)(b + d->o_s2x) + 2 * CLSMAX * 64; }
+    PM2_DEV double *cdfg() const { return (double *)(b + d->o_cdf); }                    // CDF rows of the class slots beyond the LDS rows: [slot][N + 2]        // ... and their ids (at most CLSMAX * N <= CLSMAX * 64 entries each)
 };
 
 struct DV {      // view of one dataset: LDS block + arena
@@ -358,7 +360,11 @@ struct DV {      // view of one dataset: LDS block + arena
     PM2_DEV void slot_set(int id, int s) const { if (id < idcap) lds<u8>(base + lay->slotmap)[id] = (u8)s; }
     PM2_DEV double *ta_row(int j) const { return lds<double>(base + lay->ta) + j * Dp; }
     PM2_DEV double *tb_row(int j) const { return lds<double>(trb + lay->tr_tb) + j * Dp; }
-    PM2_DEV double *cdf_row(int r) const { return lds<double>(trb + lay->tr_cdf) + r * (N + 2); }
+    // mutation CDF of class slot r: entries [0, N) the CDF, [N] the log-increment, [N + 1] the one-hot label or -1.  The first cdfl slots'
+    // rows live in LDS, the others (a step with that many classes is rare) in the chain's arena
+    PM2_DEV double *cdf_row_l(int r) const { return lds<double>(trb + lay->tr_cdf) + r * (N + 2); }
+    PM2_DEV double cdf_get(int r, int j) const { if (r < lay->cdfl) return cdf_row_l(r)[j]; return PM2_G(const double, ar.cdfg())[(size_t)r * (N + 2) + j]; }
+    PM2_DEV void cdf_set(int r, int j, double x) const { if (r < lay->cdfl) cdf_row_l(r)[j] = x; else PM2_G(double, ar.cdfg())[(size_t)r * (N + 2) + j] = x; }
     PM2_DEV double *lp() const { return lds<double>(base + lay->lp); }
     // row j of the step's log-predictives: cache slots [0, NS), then the uncached clusters in the order they were listed
     PM2_DEV double lp_get(int j) const { if (j < NS + XCAP) return lp()[j]; return PM2_G(const double, ar.lpx())[j - NS - XCAP]; }
@@ -954,15 +960,14 @@ struct Sweep2 {
                 const u64 m_one = PM2_BALLOT(valid && (cd == 1.0 || nn == N - 1));
                 const u64 m_tiny = PM2_BALLOT(valid && cd < 0x1p-53);
                 if (valid) {
-                    double *row = v.cdf_row(r);
-                    row[nn] = cd;
+                    v.cdf_set(r, nn, cd);
                     if (nn == N - 1) {
-                        row[N] = log(fN) + m;
+                        v.cdf_set(r, N, log(fN) + m);
                         const u64 grp = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << gbase);
                         const int nstar = pm2_ffs64((m_one & grp) >> gbase) - 1;
                         const u64 below = (nstar == 0) ? 0ull : ((1ull << nstar) - 1ull);
                         const bool onehot = (((m_tiny & grp) >> gbase) & below) == below;
-                        row[N + 1] = onehot ? (double)nstar : -1.0;
+                        v.cdf_set(r, N + 1, onehot ? (double)nstar : -1.0);
                     }
                 }
                 PM2_WAVE_BARRIER();
@@ -1988,9 +1993,8 @@ struct Sweep2 {
                     const int p = tid * PPL + u;
                     r_[u] = csl_get(k, u);
                     cl_[u] = (int)((colp[k * NCP + (u >> 1)] >> ((u & 1) * 16)) & 0xffffu);
-                    const double *row = v.cdf_row(r_[u]);
-                    const int hot = (int)row[N + 1];
-                    inc_[u] = row[N];
+                    const int hot = (int)v.cdf_get(r_[u], N + 1);
+                    inc_[u] = v.cdf_get(r_[u], N);
                     const int ns = (p == 0) ? ns0 : hot;                        // reference trajectory (:262); one-hot CDF: no random number needed
                     nsv.set(u, ns);
                     draw_any |= ns < 0;
@@ -2001,15 +2005,21 @@ struct Sweep2 {
                     for (int u = 0; u < PPL; ++u) {
                         if (nsv[u] < 0) {
                             const int p = tid * PPL + u;
-                            const double *row = v.cdf_row(csl_get(k, u));
+                            const int rr = csl_get(k, u);
                             const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
                             // first label whose CDF exceeds u (:252-260) = the number of leading entries that do not exceed it
                             int ns = 0, t = 0;
-                            for (; t + 4 <= N - 1; t += 4) {          // four LDS reads in flight
-                                const double a0 = row[t], a1 = row[t + 1], a2 = row[t + 2], a3 = row[t + 3];
-                                ns += ((a0 > u01) ? 0 : 1) + ((a1 > u01) ? 0 : 1) + ((a2 > u01) ? 0 : 1) + ((a3 > u01) ? 0 : 1);
+                            if (rr < L.cdfl) {
+                                const double *row = v.cdf_row_l(rr);
+                                for (; t + 4 <= N - 1; t += 4) {          // four LDS reads in flight
+                                    const double a0 = row[t], a1 = row[t + 1], a2 = row[t + 2], a3 = row[t + 3];
+                                    ns += ((a0 > u01) ? 0 : 1) + ((a1 > u01) ? 0 : 1) + ((a2 > u01) ? 0 : 1) + ((a3 > u01) ? 0 : 1);
+                                }
+                                for (; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
+                            } else {                                      // (a class slot beyond the LDS rows: its CDF from the arena)
+                                auto row = PM2_G(const double, v.ar.cdfg()) + (size_t)rr * (N + 2);
+                                for (; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
                             }
-                            for (; t < N - 1; ++t) ns += (row[t] > u01) ? 0 : 1;
                             nsv.set(u, ns);
                         }
                     }

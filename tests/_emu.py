@@ -35,7 +35,7 @@ def lib(variant=""):
         L = C.CDLL(build(variant=variant))
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.emu_create.restype = vp
-        L.emu_create.argtypes = [i32, i64, i32, i32, vp, vp, C.c_uint64, i32, i32, i32, vp, i32]
+        L.emu_create.argtypes = [i32, i64, i32, i32, vp, vp, C.c_uint64, i32, i32, i32, vp, i32, i32]
         L.emu_destroy.argtypes = [vp]
         L.emu_lds_bytes.restype = i64
         L.emu_lds_bytes.argtypes = [vp]
@@ -52,7 +52,7 @@ def _ptr(a):
 class EmuSweeper:
     """One chain of the settled-chain kernel on the emulator; same call shape as the oracle's Oracle.sweep."""
 
-    def __init__(self, data, N, P, seed=0, q1_mode=0, cols_l=64, idcap=128, variant="", kinds=None, cls=16):
+    def __init__(self, data, N, P, seed=0, q1_mode=0, cols_l=64, idcap=128, variant="", kinds=None, cls=16, cdfl=0):
         self._L = lib(variant)
         self.K, self.n, self.N, self.P = len(data), int(data[0].shape[0]), int(N), int(P)
         self.D = np.array([x.shape[1] for x in data], dtype=np.int32)
@@ -61,7 +61,7 @@ class EmuSweeper:
         code = {"gaussian": 0, "categorical": 1, "negbinom": 2}
         self._kinds = np.array([code[k] for k in (kinds or ["gaussian"] * self.K)], dtype=np.int32)
         self.h = self._L.emu_create(self.K, self.n, self.N, self.P, _ptr(self.D), C.cast(ptrs, C.c_void_p), int(seed), int(q1_mode),
-                                  int(cols_l), int(idcap), _ptr(self._kinds), int(cls))
+                                  int(cols_l), int(idcap), _ptr(self._kinds), int(cls), int(cdfl))
         if not self.h:
             raise ValueError("emu_create rejected the configuration")
         self.lds_bytes = self._L.emu_lds_bytes(self.h)

@@ -55,7 +55,7 @@ struct Emu {
     std::vector<std::vector<char>> arena;
     DsetDev ds[PMDI_KMAX_I];
     int Dmax = 0, sumD = 0;
-    int cols_l, idcap, cls;
+    int cols_l, idcap, cls, cdfl;
 };
 
 struct RunArg { const SweepArgs *a; int K, PPL, NW; };
@@ -85,7 +85,7 @@ extern "C" {
 
 // data[k]: n x D_k row-major doubles (integer types: levels 1..L / counts >= 0 as doubles); kinds[k]: K_GAUSSIAN / K_CATEGORICAL / K_NEGBINOM
 void *emu_create(int K, long long n, int N, int P, const int *D, const double *const *data, unsigned long long seed, int q1,
-                 int cols_l, int idcap, const int *kinds, int cls)
+                 int cols_l, int idcap, const int *kinds, int cls, int cdfl)
 {
     if (K < 1 || K > pmdi_s2::KMAX2 || (P != 256 && P != 512 && P != 1024 && P != 2048) || N > 64) return nullptr;
     Emu *e = new Emu();
@@ -95,7 +95,7 @@ void *emu_create(int K, long long n, int N, int P, const int *D, const double *c
         const int mx = pmdi_s2::class_slots_max(K, P / (64 * nw), nw);
         if (cls > mx) cls = mx;
     }
-    e->cols_l = cols_l; e->idcap = idcap; e->cls = cls;
+    e->cols_l = cols_l; e->idcap = idcap; e->cls = cls; e->cdfl = (cdfl > 0 && cdfl < cls) ? cdfl : cls;
     memset(e->ds, 0, sizeof(e->ds));
     e->x.resize(K); e->gtab.resize(K); e->arena.resize(K); e->lhtab.resize(K); e->lgtab.resize(K); e->xi.resize(K); e->maxcol.resize(K);
     int flag_off = 0;
@@ -159,7 +159,7 @@ long long emu_lds_bytes(void *h)
 {
     Emu *e = (Emu *)h;
     S2Layout L;
-    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, e->cls, L);
+    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, e->cls, e->cdfl, L);
     return L.total;
 }
 
@@ -183,7 +183,7 @@ int emu_sweep(void *h, long long iter, const int *s_in, const int *order, long l
     std::vector<int> kstate(PMDI_KMAX_I * 2, 0);
     std::vector<long long> wk(PMDI_KMAX_I * 8, 0);
     a.err = &err; a.cost = &cost; a.kstate = kstate.data(); a.work = wk.data();
-    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, e->cls, a.s2);
+    pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, e->cls, e->cdfl, a.s2);
     const int nw = e->P > 1024 ? 8 : 4;
     RunArg r{&a, e->K, e->P / (64 * nw), nw};
     wavesim::run_block(64 * nw, 0, (size_t)a.s2.total, entry, &r);

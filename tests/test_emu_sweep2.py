@@ -35,12 +35,12 @@ def _mixed(rng, n, kinds, sep=3.0):
     return data, z
 
 
-def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0, variant="", kinds=None, cls=16):
+def _compare(O, data, N, P, iters, seed, n1, q1=0, flags=None, cols_l=64, idcap=128, settle=False, truth=None, scramble=0.05, allow_requeue=0, variant="", kinds=None, cls=16, cdfl=0):
     from _emu import EmuSweeper
     rng = np.random.default_rng(seed)
     n, K = data[0].shape[0], len(data)
     kinds = kinds or ["gaussian"] * K
-    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant, kinds=kinds, cls=cls)
+    e = EmuSweeper(data, N, P, seed=seed, q1_mode=q1, cols_l=cols_l, idcap=idcap, variant=variant, kinds=kinds, cls=cls, cdfl=cdfl)
     o = O.Oracle(data, kinds, N, P, seed=seed, q1_mode=q1)
     rec = o.debug_steps(n - n1 + 1)
     requeued = []
@@ -174,6 +174,9 @@ def test_up_to_32_particle_classes_per_dataset(O):
         _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=16)
     rec = _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=32)
     assert 16 < rec[:, :, 0].max() <= 32, rec[:, :, 0].max()
+    # ... and with the CDF rows of the class slots beyond the first 16 (or 4) in the chain's arena instead of LDS
+    for cdfl in (16, 4):
+        _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=32, cdfl=cdfl)
 
 
 def test_eight_wave_workgroup_for_2048_particles(O):
