@@ -673,8 +673,8 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
                 // step with that many classes is rare, a hand-over costs the rest of the chain's sweep at the general kernel's speed)
                 int cdfl = cls;
                 pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, cdfl, &h->s2);
-                if ((size_t)h->s2.total > budget && cls > 16) { cdfl = 16; pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, cdfl, &h->s2); }
-                while ((size_t)h->s2.total > budget && cls > 16) { cls -= 4; pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, cdfl, &h->s2); }
+                if ((size_t)h->s2.total > budget && cls > 16 && pmdi_sweep2_cdf_arena(K, P)) { cdfl = 16; pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, cdfl, &h->s2); }
+                while ((size_t)h->s2.total > budget && cls > 16) { cls -= 4; if (cdfl > cls) cdfl = cls; pmdi_sweep2_layout(K, N, P, h->Dmax, cols_l, idcap, cls, cdfl, &h->s2); }
                 while ((size_t)h->s2.total > budget && (cols_l > 16 || idcap > 64)) {
                     // (a settled chain holds 6-40 columns and ids below ~40 at the 99th percentile of its steps: the id tables go first)
                     if (idcap > 96) idcap -= 16; else if (cols_l > 32) cols_l -= 8; else if (idcap > 64) idcap -= 16; else cols_l -= 8;

@@ -212,6 +212,7 @@ hipError_t pmdi_sweep_blocks_per_cu(const SweepArgs &a, int T, int *blocks);
 void pmdi_sweep2_layout(int K, int N, int P, int Dmax, int cols_l, int idcap, int cls, int cdfl, S2Layout *L);
 bool pmdi_sweep2_supports(int K, int N, int P, int Dmax, long long cap);
 int pmdi_sweep2_threads(int K, int P);
+bool pmdi_sweep2_cdf_arena(int K, int P);     // that shape's build takes S2Layout::cdfl < cls
 int pmdi_sweep2_max_classes(int K, int P);  // particle classes per dataset the class slots of that shape can name (16 or 32)      // threads of the workgroup that sweeps a chain of P particles (0: no build for it)
 hipError_t pmdi_sweep2_blocks_per_cu(const SweepArgs &a, int *blocks);
 hipError_t pmdi_launch_sweep2(const SweepArgs &a, SweepArgs *d_args, int n_chains, hipStream_t stream, SweepArgs *staging = nullptr);

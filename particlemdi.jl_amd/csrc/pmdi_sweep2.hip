@@ -72,6 +72,13 @@ int pmdi_sweep2_max_classes(int K, int P)
     return pmdi_s2::class_slots_max(K, P / (64 * nw), nw);
 }
 
+// whether that shape's build lets the mutation-CDF rows of the class slots beyond S2Layout::cdfl continue in the chain's arena
+bool pmdi_sweep2_cdf_arena(int K, int P)
+{
+    int nw = 0;
+    return kernel_for(K, P, &nw) && pmdi_s2::cdf_rows_in_arena(nw);
+}
+
 int pmdi_sweep2_threads(int K, int P)
 {
     int nw = 0;

@@ -223,6 +223,10 @@ constexpr int CLSMAX = 32;      // particle classes per dataset the class slots 
 // two-word form cost that kernel 5 % per step), else five -- one word per dataset
 PM2_HD constexpr int class_slot_bits(int K, int PPL, int NW) { return (K == 4 && PPL == 4 && NW == 4) ? 4 : 5; }
 PM2_HD constexpr int class_slots_max(int K, int PPL, int NW) { return 1 << class_slot_bits(K, PPL, NW); }
+// builds whose mutation-CDF rows may continue in the chain's arena (class slots >= Layout::cdfl): the 8-wave ones, whose N = 50
+// tables would otherwise hold 24 classes; the 4-wave builds keep every row in LDS and carry no code for the other case (the
+// branches cost the headline kernel 3-5 % when they were there)
+PM2_HD constexpr bool cdf_rows_in_arena(int NW) { return NW > 4; }
 constexpr int KCAPMAX = 256;    // (class, label) keys a step may touch at most (the key lists of the bookkeeping phase; Layout::kcap)
 constexpr int RI_CLSMIN = 64, RI_NEWSLOT = 96, RI_CLSVAL = 128;     // resampling: per-class scratch (CLSMAX ints each), int offsets into the reduction area
 constexpr int RI_WCNT = 160;                                         // ... and per-wave counts of the block scans (NWMAX ints)
@@ -324,7 +328,7 @@ struct Arena {   // the chain's arrays of one dataset in global memory (what exc
 struct DV {      // view of one dataset: LDS block + arena
     int base;            // LDS offset of the dataset block
     int trb;             // LDS offset of its transient rows
-    int N, P, D, Dp, cols_l, idcap;
+    int N, P, D, Dp, cols_l, idcap, cdfl;
     int kind, Lc;        // cluster type of the dataset (K_GAUSSIAN / K_CATEGORICAL / K_NEGBINOM); Categorical: levels per feature in the pool
     const PM2_CONST Layout *lay;
     Arena ar;
@@ -363,8 +367,6 @@ struct DV {      // view of one dataset: LDS block + arena
     // mutation CDF of class slot r: entries [0, N) the CDF, [N] the log-increment, [N + 1] the one-hot label or -1.  The first cdfl slots'
     // rows live in LDS, the others (a step with that many classes is rare) in the chain's arena
     PM2_DEV double *cdf_row_l(int r) const { return lds<double>(trb + lay->tr_cdf) + r * (N + 2); }
-    PM2_DEV double cdf_get(int r, int j) const { if (r < lay->cdfl) return cdf_row_l(r)[j]; return PM2_G(const double, ar.cdfg())[(size_t)r * (N + 2) + j]; }
-    PM2_DEV void cdf_set(int r, int j, double x) const { if (r < lay->cdfl) cdf_row_l(r)[j] = x; else PM2_G(double, ar.cdfg())[(size_t)r * (N + 2) + j] = x; }
     PM2_DEV double *lp() const { return lds<double>(base + lay->lp); }
     // row j of the step's log-predictives: cache slots [0, NS), then the uncached clusters in the order they were listed
     PM2_DEV double lp_get(int j) const { if (j < NS + XCAP) return lp()[j]; return PM2_G(const double, ar.lpx())[j - NS - XCAP]; }
@@ -417,6 +419,9 @@ struct Sweep2 {
     RegArr<unsigned, K * NCP> colp;      // [k * NCP + j]: column index of the lane's particles per dataset, 16 bits each
     // class slot of the lane's particles, CSB bits each: in ONE 64-bit word (bit offset CSB * (k * PPL + u)) when they all fit,
     // else one word per dataset (32 bits while that fits; bit offset CSB * u)
+    static constexpr bool CDFA = cdf_rows_in_arena(NW);
+    PM2_DEV double cdf_get(const DV &v, int r, int j) const { if (!CDFA || r < v.cdfl) return v.cdf_row_l(r)[j]; return PM2_G(const double, v.ar.cdfg())[(size_t)r * (N + 2) + j]; }
+    PM2_DEV void cdf_set(const DV &v, int r, int j, double x) const { if (!CDFA || r < v.cdfl) v.cdf_row_l(r)[j] = x; else PM2_G(double, v.ar.cdfg())[(size_t)r * (N + 2) + j] = x; }
     static constexpr int CSB = class_slot_bits(K, PPL, NW);
     static constexpr bool ONEWORD = CSB * K * PPL <= 64;
     static constexpr int NCSW = ONEWORD ? 1 : K;
@@ -490,7 +495,7 @@ struct Sweep2 {
     {
         DV v;
         v.base = L.ds0 + k * L.ds_stride; v.trb = L.tr + k * L.tr_stride;
-        v.N = N; v.P = P; v.D = ap->ds[k].D; v.kind = ap->ds[k].kind; v.Lc = ds_levels(ap->ds[k]); v.Dp = L.Dp; v.cols_l = L.cols_l; v.idcap = L.idcap; v.lay = &ap->s2;
+        v.N = N; v.P = P; v.D = ap->ds[k].D; v.kind = ap->ds[k].kind; v.Lc = ds_levels(ap->ds[k]); v.Dp = L.Dp; v.cols_l = L.cols_l; v.idcap = L.idcap; v.cdfl = L.cdfl; v.lay = &ap->s2;
         v.ar.d = &ap->ds[k];
         v.ar.b = ap->ds[k].arena + (size_t)chain * ap->ds[k].stride;
         return v;
@@ -960,14 +965,14 @@ struct Sweep2 {
                 const u64 m_one = PM2_BALLOT(valid && (cd == 1.0 || nn == N - 1));
                 const u64 m_tiny = PM2_BALLOT(valid && cd < 0x1p-53);
                 if (valid) {
-                    v.cdf_set(r, nn, cd);
+                    cdf_set(v, r, nn, cd);
                     if (nn == N - 1) {
-                        v.cdf_set(r, N, log(fN) + m);
+                        cdf_set(v, r, N, log(fN) + m);
                         const u64 grp = (N == 64) ? ~0ull : (((1ull << N) - 1ull) << gbase);
                         const int nstar = pm2_ffs64((m_one & grp) >> gbase) - 1;
                         const u64 below = (nstar == 0) ? 0ull : ((1ull << nstar) - 1ull);
                         const bool onehot = (((m_tiny & grp) >> gbase) & below) == below;
-                        v.cdf_set(r, N + 1, onehot ? (double)nstar : -1.0);
+                        cdf_set(v, r, N + 1, onehot ? (double)nstar : -1.0);
                     }
                 }
                 PM2_WAVE_BARRIER();
@@ -1993,8 +1998,8 @@ struct Sweep2 {
                     const int p = tid * PPL + u;
                     r_[u] = csl_get(k, u);
                     cl_[u] = (int)((colp[k * NCP + (u >> 1)] >> ((u & 1) * 16)) & 0xffffu);
-                    const int hot = (int)v.cdf_get(r_[u], N + 1);
-                    inc_[u] = v.cdf_get(r_[u], N);
+                    const int hot = (int)cdf_get(v, r_[u], N + 1);
+                    inc_[u] = cdf_get(v, r_[u], N);
                     const int ns = (p == 0) ? ns0 : hot;                        // reference trajectory (:262); one-hot CDF: no random number needed
                     nsv.set(u, ns);
                     draw_any |= ns < 0;
@@ -2009,7 +2014,7 @@ struct Sweep2 {
                             const double u01 = pmdi_arith::uniform01(seed, iter, (unsigned)pos, (unsigned)k, (unsigned)p, SITE_DRAW);
                             // first label whose CDF exceeds u (:252-260) = the number of leading entries that do not exceed it
                             int ns = 0, t = 0;
-                            if (rr < L.cdfl) {
+                            if (!CDFA || rr < v.cdfl) {
                                 const double *row = v.cdf_row_l(rr);
                                 for (; t + 4 <= N - 1; t += 4) {          // four LDS reads in flight
                                     const double a0 = row[t], a1 = row[t + 1], a2 = row[t + 2], a3 = row[t + 3];

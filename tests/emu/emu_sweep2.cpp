@@ -95,7 +95,8 @@ void *emu_create(int K, long long n, int N, int P, const int *D, const double *c
         const int mx = pmdi_s2::class_slots_max(K, P / (64 * nw), nw);
         if (cls > mx) cls = mx;
     }
-    e->cols_l = cols_l; e->idcap = idcap; e->cls = cls; e->cdfl = (cdfl > 0 && cdfl < cls) ? cdfl : cls;
+    e->cols_l = cols_l; e->idcap = idcap; e->cls = cls;
+    e->cdfl = (cdfl > 0 && cdfl < cls && pmdi_s2::cdf_rows_in_arena(P > 1024 ? 8 : 4)) ? cdfl : cls;     // (only the 8-wave builds carry that path)
     memset(e->ds, 0, sizeof(e->ds));
     e->x.resize(K); e->gtab.resize(K); e->arena.resize(K); e->lhtab.resize(K); e->lgtab.resize(K); e->xi.resize(K); e->maxcol.resize(K);
     int flag_off = 0;

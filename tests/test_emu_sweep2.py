@@ -174,9 +174,11 @@ def test_up_to_32_particle_classes_per_dataset(O):
         _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=16)
     rec = _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=32)
     assert 16 < rec[:, :, 0].max() <= 32, rec[:, :, 0].max()
-    # ... and with the CDF rows of the class slots beyond the first 16 (or 4) in the chain's arena instead of LDS
+    # ... and, in the 8-wave build (P = 2 048), with the CDF rows of the class slots beyond the first 16 (or 4) in the chain's arena
+    # instead of LDS: how cfg4's N = 50 tables hold 32 classes
     for cdfl in (16, 4):
-        _compare(O, data, 40, 512, 1, 94, 40, settle=0.5, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=32, cdfl=cdfl)
+        rec = _compare(O, data, 40, 2048, 1, 96, 40, settle=1.0, truth=z, allow_requeue=0, kinds=["gaussian", "categorical"], scramble=0.1, cls=32, cdfl=cdfl)
+        assert rec[:, :, 0].max() > 16, rec[:, :, 0].max()
 
 
 def test_eight_wave_workgroup_for_2048_particles(O):
