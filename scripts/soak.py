@@ -13,7 +13,7 @@ def run(budget, seed, max_cases=10**9, verbose=True):
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     ncase = 0
-    saved = {k: os.environ.get(k) for k in ("PMDI_LIGHT_IDS", "PMDI_VERY_HEAVY", "PMDI_KSPLIT")}
+    saved = {k: os.environ.get(k) for k in ("PMDI_LIGHT_IDS", "PMDI_VERY_HEAVY", "PMDI_KSPLIT", "PMDI_SETTLED", "PMDI_S2_CLS", "PMDI_STICKY")}
     try:
         while time.time() < t_end and ncase < max_cases:
             ncase += _one_case(rng)
@@ -38,6 +38,11 @@ def _one_case(rng):
     if os.environ.get("PMDI_SOAK_BIG"):       # fewer, larger cases: more particles, labels, datasets, observations
         K = int(rng.integers(1, 5)); n = int(rng.integers(150, 500)); N = int(rng.integers(10, 51)); P = int(rng.choice([512, 1024, 2048, 4096]))
     block = int(rng.choice([0, 0, 0, 128, 256, 512, 1024])); n1 = int(rng.integers(1, n + 1)); iters = int(rng.integers(1, 5))
+    # the settled-chain kernel (where the shape has it): after a chain's first sweep or from the first sweep on (then the random start
+    # hands every chain over to the general kernel's code mid-sweep), 16 or up to 32 particle classes in its tables, sticky or not
+    os.environ["PMDI_SETTLED"] = str(int(rng.choice([1, 2, 2])))
+    os.environ["PMDI_S2_CLS"] = str(int(rng.choice([16, 32])))
+    os.environ["PMDI_STICKY"] = str(int(rng.choice([0, 3])))
     os.environ["PMDI_LIGHT_IDS"] = str(int(rng.choice([2, 10, 40, 400])))
     os.environ["PMDI_VERY_HEAVY"] = str(int(rng.choice([0, 1, 2, 128])))
     z = rng.integers(0, 3, n); sep = float(rng.choice([0.0, 1.0, 3.0]))
@@ -51,7 +56,7 @@ def _one_case(rng):
     sumD = sum(d.shape[1] for d in data)
     flags = (rng.random((Cn, sumD)) < 0.7).astype(np.uint8) if rng.random() < 0.3 else None
     seed = int(rng.integers(0, 2**31))
-    desc = f"K={K} n={n} N={N} P={P} C={Cn} q1={q1} T={block} n1={n1} it={iters} kinds={kinds} sep={sep} light={os.environ['PMDI_LIGHT_IDS']} vh={os.environ['PMDI_VERY_HEAVY']} flags={'y' if flags is not None else 'n'} q2={q2} split={os.environ['PMDI_KSPLIT']} seed={seed}"
+    desc = f"K={K} n={n} N={N} P={P} C={Cn} q1={q1} T={block} n1={n1} it={iters} kinds={kinds} sep={sep} light={os.environ['PMDI_LIGHT_IDS']} settled={os.environ['PMDI_SETTLED']} cls={os.environ['PMDI_S2_CLS']} sticky={os.environ['PMDI_STICKY']} vh={os.environ['PMDI_VERY_HEAVY']} flags={'y' if flags is not None else 'n'} q2={q2} split={os.environ['PMDI_KSPLIT']} seed={seed}"
     try:
         sw = pkg.Sweeper(data, kinds, N, P, n_chains=Cn, seed=seed, q1_mode=q1, q2_mode=q2, block_threads=block)
     except Exception as e:
