@@ -21,7 +21,7 @@ namespace {
 // Two waves per SIMD whatever the workgroup's width (64 * NW threads: two 256-thread workgroups per CU, or one of 512) -- the second
 // launch bound is hipcc's waves-per-SIMD floor -- so a wave may use up to 256 VGPRs.  The particle state and the cluster cache of a wave live in registers for the whole sweep; the builds' spill
 // counts are pinned by tests/test_build_budget.py.
-template <int K, int PPL, int NW>
+template <int K, int PPL, int NW, bool GO>
 __global__ void __launch_bounds__(64 * NW, 2) pmdi_sweep2_kernel(const SweepArgs *__restrict__ ap)
 {
     const SweepArgs &a = *ap;
@@ -29,32 +29,44 @@ __global__ void __launch_bounds__(64 * NW, 2) pmdi_sweep2_kernel(const SweepArgs
     const int chain = a.chain_order ? a.chain_order[bslot] : bslot;
     // the chains of a sweep are shared out between launches by what their previous sweep looked like (pmdi_api.cpp)
     if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || bslot < a.rank_lo || bslot >= a.rank_hi)) return;
-    pmdi_s2::Sweep2<K, PPL, NW> s;
+    pmdi_s2::Sweep2<K, PPL, NW, GO> s;
     s.run(ap, chain);
 }
 
 // the instantiations: P = 256 / 512 / 1024 particles on four waves (1, 2, 4 particles per lane), P = 2048 on eight waves (4 per lane)
+// (gauss_only: every dataset of the handle is Gaussian -- the build without the integer cluster types' code; 4-wave shapes only)
 template <int K>
-const void *kernel_for_k(int P, int *nw)
+const void *kernel_for_k(int P, int *nw, bool gauss_only)
 {
     *nw = 4;
-    if (P == 256) return (const void *)pmdi_sweep2_kernel<K, 1, 4>;
-    if (P == 512) return (const void *)pmdi_sweep2_kernel<K, 2, 4>;
-    if (P == 1024) return (const void *)pmdi_sweep2_kernel<K, 4, 4>;
+    if (gauss_only) {
+        if (P == 256) return (const void *)pmdi_sweep2_kernel<K, 1, 4, true>;
+        if (P == 512) return (const void *)pmdi_sweep2_kernel<K, 2, 4, true>;
+        if (P == 1024) return (const void *)pmdi_sweep2_kernel<K, 4, 4, true>;
+    }
+    if (P == 256) return (const void *)pmdi_sweep2_kernel<K, 1, 4, false>;
+    if (P == 512) return (const void *)pmdi_sweep2_kernel<K, 2, 4, false>;
+    if (P == 1024) return (const void *)pmdi_sweep2_kernel<K, 4, 4, false>;
     *nw = 8;
-    if (P == 2048) return (const void *)pmdi_sweep2_kernel<K, 4, 8>;
+    if (P == 2048) return (const void *)pmdi_sweep2_kernel<K, 4, 8, false>;
     return nullptr;
 }
 
-const void *kernel_for(int K, int P, int *nw)
+const void *kernel_for(int K, int P, int *nw, bool gauss_only = false)
 {
     switch (K) {
-    case 1: return kernel_for_k<1>(P, nw);
-    case 2: return kernel_for_k<2>(P, nw);
-    case 3: return kernel_for_k<3>(P, nw);
-    case 4: return kernel_for_k<4>(P, nw);
+    case 1: return kernel_for_k<1>(P, nw, gauss_only);
+    case 2: return kernel_for_k<2>(P, nw, gauss_only);
+    case 3: return kernel_for_k<3>(P, nw, gauss_only);
+    case 4: return kernel_for_k<4>(P, nw, gauss_only);
     }
     return nullptr;
+}
+
+bool all_gaussian(const SweepArgs &a)
+{
+    for (int k = 0; k < a.K; ++k) if (a.ds[k].kind != K_GAUSSIAN) return false;
+    return true;
 }
 
 }  // namespace
@@ -105,7 +117,7 @@ static size_t launch_lds(const SweepArgs &a, int nw)
 hipError_t pmdi_sweep2_blocks_per_cu(const SweepArgs &a, int *blocks)
 {
     int nw = 0;
-    const void *fn = kernel_for(a.K, a.P, &nw);
+    const void *fn = kernel_for(a.K, a.P, &nw, all_gaussian(a));
     if (!fn) return hipErrorInvalidValue;
     const size_t lds = launch_lds(a, nw);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -118,7 +130,7 @@ hipError_t pmdi_launch_sweep2(const SweepArgs &a_in, SweepArgs *d_args, int n_ch
     SweepArgs a = a_in;
     a.n_slots = n_chains;
     int nw = 0;
-    const void *fn = kernel_for(a.K, a.P, &nw);
+    const void *fn = kernel_for(a.K, a.P, &nw, all_gaussian(a));
     if (!fn) return hipErrorInvalidValue;
     const size_t lds = launch_lds(a, nw);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

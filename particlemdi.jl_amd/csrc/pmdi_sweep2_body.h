@@ -403,13 +403,15 @@ struct RegArr<Tp, 1> {
 // (the levels per feature of a Categorical dataset's pool rows: read here, ahead of the layout shorthand `L` of the struct below)
 template <class Ds> PM2_DEV int ds_levels(const Ds &d) { return d.L; }
 
-template <int K, int PPL, int NW> struct Sweep2;
+template <int K, int PPL, int NW, bool GO> struct Sweep2;
 // (cold paths of the sweep as out-of-line functions on a COPY of the sweep's per-lane state: inlined, their code cost the sweep loop
 // twenty spilled registers)
-template <int K, int PPL, int NW> PM2_COLD void hand_over_cold(Sweep2<K, PPL, NW> s, long long pos, int fcode, long long t_start);
+template <int K, int PPL, int NW, bool GO> PM2_COLD void hand_over_cold(Sweep2<K, PPL, NW, GO> s, long long pos, int fcode, long long t_start);
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-template <int K, int PPL, int NW>
+// GO ("Gaussian only"): a build for handles whose datasets are all Gaussian -- every cluster-type switch folds at compile time and the
+// integer types' code is not in the kernel (the headline shape's kernel is as it was before those types arrived)
+template <int K, int PPL, int NW, bool GO>
 struct Sweep2 {
     static constexpr int T = 64 * NW;       // threads of the workgroup: NW waves, the first K of them own a dataset each
     static_assert(NW >= K && NW <= NWMAX, "one owner wave per dataset");
@@ -495,7 +497,7 @@ struct Sweep2 {
     {
         DV v;
         v.base = L.ds0 + k * L.ds_stride; v.trb = L.tr + k * L.tr_stride;
-        v.N = N; v.P = P; v.D = ap->ds[k].D; v.kind = ap->ds[k].kind; v.Lc = ds_levels(ap->ds[k]); v.Dp = L.Dp; v.cols_l = L.cols_l; v.idcap = L.idcap; v.cdfl = L.cdfl; v.lay = &ap->s2;
+        v.N = N; v.P = P; v.D = ap->ds[k].D; v.kind = GO ? (int)K_GAUSSIAN : ap->ds[k].kind; v.Lc = ds_levels(ap->ds[k]); v.Dp = L.Dp; v.cols_l = L.cols_l; v.idcap = L.idcap; v.cdfl = L.cdfl; v.lay = &ap->s2;
         v.ar.d = &ap->ds[k];
         v.ar.b = ap->ds[k].arena + (size_t)chain * ap->ds[k].stride;
         return v;
@@ -514,7 +516,7 @@ struct Sweep2 {
     {
         const auto &d = ap->ds[k];
         if (lane >= d.D) return 0.0;
-        if (d.kind == K_GAUSSIAN) return PM2_G(const double, d.xf)[(size_t)i * d.D + lane];
+        if (GO || d.kind == K_GAUSSIAN) return PM2_G(const double, d.xf)[(size_t)i * d.D + lane];
         return (double)PM2_G(const int, d.xi)[(size_t)i * d.D + lane];
     }
     PM2_DEV St st_load(const DV &v, int id, double x, bool act) const
@@ -522,10 +524,10 @@ struct Sweep2 {
         St st;
         st.a = 0.0; st.b = 0.5;
         if (!act) return st;
-        if (v.kind == K_GAUSSIAN) {
+        if ((GO || v.kind == K_GAUSSIAN)) {
             auto sb = PM2_G(const double, v.ar.sb());
             st.a = sb[((size_t)id * v.D + lane) * 2]; st.b = sb[((size_t)id * v.D + lane) * 2 + 1];
-        } else if (v.kind == K_CATEGORICAL) {
+        } else if ((!GO && v.kind == K_CATEGORICAL)) {
             st.a = (double)PM2_G(const int, v.ar.cnt())[((size_t)id * v.D + lane) * v.Lc + ((int)x - 1)];
         } else {
             st.a = (double)PM2_G(const long long, v.ar.nbs())[(size_t)id * v.D + lane];
@@ -537,11 +539,11 @@ struct Sweep2 {
     PM2_DEV void st_add_store(const DV &v, int id, St &st, double x, int nnew, bool on) const
     {
         if (!on) return;
-        if (v.kind == K_GAUSSIAN) {
+        if ((GO || v.kind == K_GAUSSIAN)) {
             pmdi_arith::gauss_add_sb(x, nnew, st.a, st.b);
             auto sb = PM2_G(double, v.ar.sb());
             sb[((size_t)id * v.D + lane) * 2] = st.a; sb[((size_t)id * v.D + lane) * 2 + 1] = st.b;
-        } else if (v.kind == K_CATEGORICAL) {
+        } else if ((!GO && v.kind == K_CATEGORICAL)) {
             st.a = st.a + 1.0;
             PM2_G(int, v.ar.cnt())[((size_t)id * v.D + lane) * v.Lc + ((int)x - 1)] = (int)st.a;
         } else {
@@ -556,13 +558,13 @@ struct Sweep2 {
     PM2_DEV void st_terms(const DV &v, int k, int cn, const St &st, double x, double &ta, double &tb) const
     {
         const auto &d = ap->ds[k];
-        if (v.kind == K_GAUSSIAN) {
+        if ((GO || v.kind == K_GAUSSIAN)) {
             double mu, lam;
             pmdi_arith::gauss_ml(cn, st.a, st.b, mu, lam);
             const double nd_ = (double)cn, dd = x - mu;
             ta = 0.5 * log(lam / (nd_ + 1.0));
             tb = (0.5 * nd_ + 1.0) * log(1.0 + (1.0 / (nd_ + 1.0)) * (dd * dd) * lam);
-        } else if (v.kind == K_CATEGORICAL) {
+        } else if ((!GO && v.kind == K_CATEGORICAL)) {
             auto lh = PM2_G(const double, d.lhtab);
             ta = lh[PM2_G(const int, d.maxcol)[lane] + 2 * cn];
             tb = (cn == 0) ? lh[1] : lh[2 * (int)st.a + 1];
@@ -609,8 +611,8 @@ struct Sweep2 {
     // (it depends on the size only).  The integer types read their statistics from the pool at every step.
     PM2_DEV void cache_fill(const DV &v, int k, int s0, double sg, double bt, int cnv, bool defer = false, bool have_g = false, double g_in = 0.0)
     {
-        if (v.kind != K_GAUSSIAN) {
-            if (v.kind == K_CATEGORICAL && lane < v.D)
+        if ((!GO && v.kind != K_GAUSSIAN)) {
+            if ((!GO && v.kind == K_CATEGORICAL) && lane < v.D)
                 v.ta_row(s0)[lane] = PM2_G(const double, ap->ds[k].lhtab)[PM2_G(const int, ap->ds[k].maxcol)[lane] + 2 * cnv];
             if (lane == 0) lds<int>(v.base + L.slot_cn)[s0] = cnv;
             return;
@@ -691,7 +693,7 @@ struct Sweep2 {
         PM2_WAVE_BARRIER();
         // fresh clusters and the first n1-1 shuffled observations joining their previous cluster, sequentially in shuffled
         // order (:189,:194,:201-206): lane = feature, one label after the other
-        if (d.kind == K_GAUSSIAN) {
+        if (GO || d.kind == K_GAUSSIAN) {
             auto sb = PM2_G(double, v.ar.sb());
             auto xf = PM2_G(const double, d.xf);
             if (lane < D) { sb[((size_t)1 * D + lane) * 2] = 0.0; sb[((size_t)1 * D + lane) * 2 + 1] = 0.5; }
@@ -710,7 +712,7 @@ struct Sweep2 {
                 }
                 if (lane < D) { sb[((size_t)id * D + lane) * 2] = sg; sb[((size_t)id * D + lane) * 2 + 1] = bt; }
             }
-        } else if (d.kind == K_CATEGORICAL) {
+        } else if ((!GO && d.kind == K_CATEGORICAL)) {
             // counts[level, feature] (categorical_cluster.jl:43-51): the lane's feature, one level after the other (the count of a level
             // is a sum over the label's observations: no order to keep)
             auto cn_ = PM2_G(int, v.ar.cnt());
@@ -821,7 +823,7 @@ struct Sweep2 {
                             v.slot_set(id0, s0);
                         }
                         needmask |= 1u << s0;
-                        const St st0 = st_load(v, id0, x, lane < D && v.kind == K_GAUSSIAN);
+                        const St st0 = st_load(v, id0, x, lane < D && (GO || v.kind == K_GAUSSIAN));
                         cache_fill(v, k, s0, st0.a, st0.b, v.cn_get(id0));
                         row = s0;
                     } else {
@@ -849,7 +851,7 @@ struct Sweep2 {
         PHD(1);
         // -- A2: the per-feature terms, lane = feature.  Gaussian: cached clusters need one log per feature (gaussian_cluster.jl:46-48).
         // Integer types: the statistics of all needed slots from the pool (the loads in flight together), then the table look-ups
-        if (v.kind == K_GAUSSIAN) {
+        if ((GO || v.kind == K_GAUSSIAN)) {
 #pragma nounroll
             for (int s = 0; s < NS; ++s) {
                 if ((needmask >> s) & 1u) {
@@ -878,7 +880,7 @@ struct Sweep2 {
         double *lp = v.lp();
         PM2_WAVE_BARRIER();
         if (lane < NS && ((needmask >> lane) & 1u))
-            lp[lane] = ordered_sum(v.kind, v.ta_row(lane), v.tb_row(lane), D, fl, dsc[DS_NFLAG] == D, lds<double>(v.base + L.slot_g)[lane]);
+            lp[lane] = ordered_sum(GO ? (int)K_GAUSSIAN : v.kind, v.ta_row(lane), v.tb_row(lane), D, fl, dsc[DS_NFLAG] == D, lds<double>(v.base + L.slot_g)[lane]);
         PHD(3);
         // uncached reachable clusters, XR per round: statistics from the pool, both terms on the fly into the tb rows (the cached
         // clusters' sums are done with them): rows 2j, 2j + 1 for the j-th cluster of the round; then one lane per cluster adds
@@ -906,8 +908,8 @@ struct Sweep2 {
             PM2_WAVE_BARRIER();
             if (lane < XR && e0 + lane < nx) {
                 const int id = v.xid_get(e0 + lane);
-                const double g0 = (v.kind == K_GAUSSIAN) ? (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[v.cn_get(id)] : 0.0;
-                v.lp_set(NS + e0 + lane, ordered_sum(v.kind, v.tb_row(2 * lane), v.tb_row(2 * lane + 1), D, fl, false, g0));
+                const double g0 = ((GO || v.kind == K_GAUSSIAN)) ? (double)dsc[DS_NFLAG] * PM2_G(const double, d.gtab)[v.cn_get(id)] : 0.0;
+                v.lp_set(NS + e0 + lane, ordered_sum(GO ? (int)K_GAUSSIAN : v.kind, v.tb_row(2 * lane), v.tb_row(2 * lane + 1), D, fl, false, g0));
             }
         }
         PM2_WAVE_BARRIER();
@@ -1333,7 +1335,7 @@ struct Sweep2 {
                     stj[j] = pf; gj[j] = 0.0;
                     if (mine[j]) {
                         if (e0 + j > 0) stj[j] = st_load(v, cj[j], x, lane < D);
-                        if (lane == 0 && v.kind == K_GAUSSIAN) gj[j] = PM2_G(const double, d.gtab)[nj[j]];
+                        if (lane == 0 && (GO || v.kind == K_GAUSSIAN)) gj[j] = PM2_G(const double, d.gtab)[nj[j]];
                     }
                 }
 #pragma unroll
@@ -1422,7 +1424,7 @@ struct Sweep2 {
                         if (mine[j]) nj[j] = v.cn_get(tj[j]);
                     }
                 }
-                if (v.kind == K_GAUSSIAN) {
+                if ((GO || v.kind == K_GAUSSIAN)) {
 #pragma unroll
                     for (int j = 0; j < HB; ++j) {
                         sgj[j] = 0.0; btj[j] = 0.5;
@@ -1436,7 +1438,7 @@ struct Sweep2 {
                             if (lane < D && (on || tj[j] != cj[j])) { sb[((size_t)tj[j] * D + lane) * 2] = sg; sb[((size_t)tj[j] * D + lane) * 2 + 1] = bt; }
                         }
                     }
-                } else if (v.kind == K_CATEGORICAL) {
+                } else if ((!GO && v.kind == K_CATEGORICAL)) {
                     // deepcopy: every level's count of the lane's feature; cluster_add!: the observed level's (categorical_cluster.jl:43-51)
                     auto cn_ = PM2_G(int, v.ar.cnt());
                     const int Lc = v.Lc;
@@ -1785,7 +1787,7 @@ struct Sweep2 {
             if (sc()[SC_TMP0] != 0) {                         // (uniform: written before the barriers of the loop above)
                 // one pool row = W words per id: Gaussian D pairs of doubles, Categorical D x L counts, NegBinom D 64-bit sums
                 const int D = ap->ds[k].D;
-                if (v.kind == K_GAUSSIAN) {
+                if ((GO || v.kind == K_GAUSSIAN)) {
                     auto sb = PM2_G(double, v.ar.sb());
                     const long long nitems = (long long)oldmax * D;
                     for (long long b = 0; b < nitems; b += T) {
@@ -1798,7 +1800,7 @@ struct Sweep2 {
                         PM2_BARRIER();
                         if (mv) { sb[((size_t)nid * D + q) * 2] = sg; sb[((size_t)nid * D + q) * 2 + 1] = bt; }
                     }
-                } else if (v.kind == K_CATEGORICAL) {
+                } else if ((!GO && v.kind == K_CATEGORICAL)) {
                     auto cn_ = PM2_G(int, v.ar.cnt());
                     const int W = D * v.Lc;
                     const long long nitems = (long long)oldmax * W;
@@ -2377,7 +2379,7 @@ struct Sweep2 {
 #undef L
 };
 
-template <int K, int PPL, int NW> PM2_COLD void hand_over_cold(Sweep2<K, PPL, NW> s, long long pos, int fcode, long long t_start)
+template <int K, int PPL, int NW, bool GO> PM2_COLD void hand_over_cold(Sweep2<K, PPL, NW, GO> s, long long pos, int fcode, long long t_start)
 {
     s.hand_over(pos, fcode, t_start);
 }

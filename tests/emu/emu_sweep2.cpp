@@ -58,19 +58,24 @@ struct Emu {
     int cols_l, idcap, cls, cdfl;
 };
 
-struct RunArg { const SweepArgs *a; int K, PPL, NW; };
+struct RunArg { const SweepArgs *a; int K, PPL, NW; bool gauss_only; };
 
-template <int K, int PPL, int NW> void body(const SweepArgs *a)
+template <int K, int PPL, int NW> void body(const SweepArgs *a, bool gauss_only)
 {
-    pmdi_s2::Sweep2<K, PPL, NW> s;
-    s.run(a, 0);
+    if (gauss_only && NW == 4) {         // the all-Gaussian build of the 4-wave shapes (as pmdi_sweep2.hip picks it)
+        pmdi_s2::Sweep2<K, PPL, NW, true> s;
+        s.run(a, 0);
+    } else {
+        pmdi_s2::Sweep2<K, PPL, NW, false> s;
+        s.run(a, 0);
+    }
 }
 
 // the instantiations of pmdi_sweep2.hip (four waves: 1, 2, 4 particles per lane; eight waves: 4 per lane)
 void entry(void *p)
 {
     const RunArg *r = (const RunArg *)p;
-#define CASE(K_, P_, W_) if (r->K == K_ && r->PPL == P_ && r->NW == W_) return body<K_, P_, W_>(r->a)
+#define CASE(K_, P_, W_) if (r->K == K_ && r->PPL == P_ && r->NW == W_) return body<K_, P_, W_>(r->a, r->gauss_only)
     CASE(1, 1, 4); CASE(1, 2, 4); CASE(1, 4, 4); CASE(2, 1, 4); CASE(2, 2, 4); CASE(2, 4, 4); CASE(3, 1, 4); CASE(3, 2, 4); CASE(3, 4, 4);
     CASE(4, 1, 4); CASE(4, 2, 4); CASE(4, 4, 4);
     CASE(1, 4, 8); CASE(2, 4, 8); CASE(3, 4, 8); CASE(4, 4, 8);
@@ -186,7 +191,9 @@ int emu_sweep(void *h, long long iter, const int *s_in, const int *order, long l
     a.err = &err; a.cost = &cost; a.kstate = kstate.data(); a.work = wk.data();
     pmdi_s2::make_layout(e->K, e->N, e->P, e->Dmax, e->cols_l, e->idcap, e->cls, e->cdfl, a.s2);
     const int nw = e->P > 1024 ? 8 : 4;
-    RunArg r{&a, e->K, e->P / (64 * nw), nw};
+    bool go = true;
+    for (int k = 0; k < e->K; ++k) go = go && e->ds[k].kind == K_GAUSSIAN;
+    RunArg r{&a, e->K, e->P / (64 * nw), nw, go};
     wavesim::run_block(64 * nw, 0, (size_t)a.s2.total, entry, &r);
     if (work) for (int k = 0; k < e->K; ++k) for (int j = 0; j < 8; ++j) work[k * 8 + j] = wk[k * 8 + j];
     if (err == 0 && particle) {
