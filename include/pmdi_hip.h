@@ -88,7 +88,10 @@ typedef struct {
     int32_t phase_timers;   /* PMDI_PHASE_TIMERS   1: per-stage shader-clock timers (pmdi_phase_timers) */
     int32_t profiled;       /* 1: a counter-collecting profiler is attached (rocprofv3 --pmc runs the queues one kernel at a time: a launch
                              *                     that waits for another launch's workgroups would never start -- no start gate then) */
-    int32_t reserved[6];    /* -1 */
+    int32_t ticket;         /* PMDI_TICKET         0: workgroup b of the settled-chain launch sweeps chain order[b]; automatic (1): it draws its
+                             *                     position in the launch order from a counter, so the next chain goes to whichever workgroup slot
+                             *                     of the GPU frees first (the hardware deals block indices to 32 dispatch queues statically) */
+    int32_t reserved[5];    /* -1 */
 } pmdi_tuning;
 
 typedef struct {

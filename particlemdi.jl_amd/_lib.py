@@ -100,7 +100,7 @@ class _Tuning(C.Structure):
     this wrapper asks it to (pmdi_tuning_from_env) so that the PMDI_* variables keep working for tests, bench.py and the scripts."""
     _fields_ = [(name, C.c_int32) for name in (
         "settled", "continue_inplace", "sticky", "light_ids", "s2_cols", "s2_idcap", "s2_cls", "ksplit", "requeue_ksplit", "split",
-        "heavy_threads", "two_per_cu", "very_heavy", "start_gate", "terms_cap", "lds_target", "phase_timers", "profiled")] + [("reserved", C.c_int32 * 6)]
+        "heavy_threads", "two_per_cu", "very_heavy", "start_gate", "terms_cap", "lds_target", "phase_timers", "profiled", "ticket")] + [("reserved", C.c_int32 * 5)]
 
 
 class _Config(C.Structure):

@@ -151,7 +151,7 @@ struct pmdi_handle {
     DevBuf d_swept_by, d_resume;
     bool s2_continue = true;     // a chain the settled-chain kernel gives back is carried on by the general kernel at that observation
                                  // (false: swept again from the start -- the round-3 behaviour, kept for A/B runs)
-    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_args4, d_args5, d_requeue, d_requeue_total, d_handed, d_group, d_cost, d_lorder, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
+    DevBuf d_usc, d_partstar, d_kstate, d_phase, d_args, d_args2, d_args3, d_args4, d_args5, d_requeue, d_requeue_total, d_handed, d_group, d_cost, d_lorder, d_ticket, d_work, d_anclog, d_evpos, d_xcnt, d_xinc, d_xlab, d_xhdr;
     int ksplit = 0;
     int ksplit_batch = 0;        // split mode: chain slots per launch when n_chains * K workgroups are not resident at once (0 = one launch)
     bool have_order = false;
@@ -346,7 +346,10 @@ int launch_sweep_groups(pmdi_handle *h, SweepArgs &a, hipStream_t st)
             al.terms_cap = h->r_terms_cap; al.pid_lds = h->r_pid_lds; al.pp_lds = h->r_pp_lds; al.col_lds = h->r_col_lds;
             int idx;
             SweepArgs *slot = next_slot(h, h->stream2, &idx);
-            e = pmdi_launch_sweep2(al, (SweepArgs *)h->d_args4.p, C, h->stream2, slot);
+            SweepArgs as = al;
+            // its workgroups draw their positions in the launch order instead of taking blockIdx.x (SweepArgs::ticket; PMDI_TICKET=0: dealt)
+            as.ticket = (h->tun.ticket != 0) ? (int *)h->d_ticket.p : nullptr;
+            e = pmdi_launch_sweep2(as, (SweepArgs *)h->d_args4.p, C, h->stream2, slot);
             if (e == hipSuccess && idx >= 0) { e = hipEventRecord(h->ring_ev[idx], h->stream2); h->ring_used[idx] = true; }
             if (e != hipSuccess) return fail(PMDI_E_DEVICE, "sweep launch (settled chains): %s", hipGetErrorString(e));
             if (!h->s2_continue) {
@@ -406,7 +409,7 @@ void pmdi_tuning_from_env(pmdi_tuning *t)
     env("PMDI_LIGHT_IDS", t->light_ids); env("PMDI_S2_COLS", t->s2_cols); env("PMDI_S2_IDCAP", t->s2_idcap); env("PMDI_S2_CLS", t->s2_cls);
     env("PMDI_KSPLIT", t->ksplit); env("PMDI_REQUEUE_KSPLIT", t->requeue_ksplit); env("PMDI_SPLIT", t->split);
     env("PMDI_HEAVY_T", t->heavy_threads); env("PMDI_TWO_PER_CU", t->two_per_cu); env("PMDI_VERY_HEAVY", t->very_heavy);
-    env("PMDI_START_GATE", t->start_gate); env("PMDI_TERMS_CAP", t->terms_cap); env("PMDI_LDS_TARGET", t->lds_target);
+    env("PMDI_START_GATE", t->start_gate); env("PMDI_TICKET", t->ticket); env("PMDI_TERMS_CAP", t->terms_cap); env("PMDI_LDS_TARGET", t->lds_target);
     if (getenv("PMDI_PHASE_TIMERS")) t->phase_timers = 1;
     auto has = [](const char *name, const char *what) { const char *v = getenv(name); return v && strstr(v, what) != nullptr; };
     t->profiled = (has("LD_PRELOAD", "rocprof") || has("ROCP_TOOL_LIBRARIES", "rocprof") || has("HSA_TOOLS_LIB", "rocprof")) ? 1 : 0;
@@ -425,7 +428,7 @@ int pmdi_destroy(pmdi_handle *h)
     if (h->ring) (void)hipHostFree(h->ring);
     for (void *p : h->owned) (void)hipFree(p);
     DevBuf *bufs[] = {&h->d_s_in, &h->d_order, &h->d_Pi, &h->d_logphi, &h->d_flags, &h->d_s_out, &h->d_lw,
-                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_args4, &h->d_args5, &h->d_requeue, &h->d_requeue_total, &h->d_handed, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
+                      &h->d_pstar, &h->d_stats, &h->d_err, &h->d_trace, &h->d_usc, &h->d_partstar, &h->d_kstate, &h->d_phase, &h->d_args, &h->d_args2, &h->d_args3, &h->d_args4, &h->d_args5, &h->d_requeue, &h->d_requeue_total, &h->d_handed, &h->d_group, &h->d_cost, &h->d_lorder, &h->d_ticket, &h->d_work, &h->d_anclog, &h->d_evpos, &h->d_xcnt, &h->d_xinc, &h->d_xlab, &h->d_xhdr,
                       &h->d_swept_by, &h->d_resume, &h->d_traj, &h->d_lm, &h->d_firstpos, &h->d_fnull, &h->d_fflags, &h->d_fprob};
     for (DevBuf *b : bufs) b->release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -737,7 +740,7 @@ int pmdi_create(const pmdi_config *cfg, const pmdi_dataset *datasets, pmdi_handl
         (rc = h->d_kstate.ensure((size_t)C * PMDI_KMAX_I * 2 * 4)) || (rc = h->d_err.ensure((size_t)C * 4)) ||
         (rc = h->d_stats.ensure((size_t)C * 8 * 8)) || (rc = h->d_pstar.ensure((size_t)C * 4)) ||
         (rc = h->d_phase.ensure((size_t)C * 16 * 8)) || (rc = h->d_args.ensure(sizeof(SweepArgs))) ||
-        (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) ||
+        (rc = h->d_cost.ensure((size_t)C * 8)) || (rc = h->d_work.ensure((size_t)C * PMDI_KMAX_I * 8 * 8)) || (rc = h->d_lorder.ensure((size_t)C * 4)) || (rc = h->d_ticket.ensure(((size_t)C + 1) * 4)) ||
         (rc = h->d_args2.ensure(sizeof(SweepArgs))) || (rc = h->d_args3.ensure(sizeof(SweepArgs))) || (rc = h->d_group.ensure((size_t)C)) ||
         (rc = h->d_args4.ensure(sizeof(SweepArgs))) || (rc = h->d_args5.ensure(sizeof(SweepArgs))) || (rc = h->d_requeue.ensure((size_t)C * 4)) ||
         (rc = h->d_requeue_total.ensure(4 * 8)) || (rc = h->d_handed.ensure((size_t)C * 4)) || (rc = h->d_swept_by.ensure((size_t)C * 4)) ||

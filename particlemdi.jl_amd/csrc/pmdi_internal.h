@@ -146,6 +146,11 @@ struct SweepArgs {
                                 // not fit its tables, [1] mask of the datasets whose step of that observation is done, [2 + k] live columns
                                 // of dataset k; null: no continuation (a given-back chain is swept again from the start)
     int resume_mode;            // 1: this launch of the general kernel carries on the given-back chains from their hand-over records
+    int *ticket;                // settled-chain launch: [0] a counter zeroed before the launch, [1 + b] the position in the launch order
+                                // workgroup b drew from it.  The hardware deals workgroup indices to 32 dispatch queues (8 XCDs x 4 shader
+                                // engines, 16 workgroup slots each) statically, so `chain_order[blockIdx.x]` is 32 separate greedy schedules;
+                                // with a ticket the next chain of the order goes to whichever slot of the whole GPU frees first.  Null:
+                                // position = blockIdx.x
     int *swept_by;              // [chain] which kernel finished the chain's last sweep: 0 general kernel, 1 settled-chain kernel,
                                 // 2 general kernel after the settled-chain kernel gave the chain back; or null
 };

@@ -6,6 +6,7 @@
 // waiting for another launch behind this one.
 // (-DPM2_NO_RESUME_GENERAL: tests/test_build_budget.py measures this kernel's own spills -- the compiler's figure folds callees in)
 #ifndef PM2_NO_RESUME_GENERAL
+#define PMDI_BSLOT_FROM_TICKET 1
 #include "pmdi_sweep_body.h"
 template <int K, int NW>
 __device__ __noinline__ void pmdi_resume_general(const SweepArgs *ap)
@@ -25,7 +26,21 @@ template <int K, int PPL, int NW, bool GO>
 __global__ void __launch_bounds__(64 * NW, 2) pmdi_sweep2_kernel(const SweepArgs *__restrict__ ap)
 {
     const SweepArgs &a = *ap;
-    const int bslot = (int)blockIdx.x;
+    int bslot = (int)blockIdx.x;
+    if (a.ticket) {
+        // the workgroup's position in the launch order is drawn, not blockIdx.x (SweepArgs::ticket): one atomic per workgroup; the
+        // general kernel's code finds it under 1 + blockIdx.x if this workgroup has to carry its chain on
+        int *tk = (int *)pm2_smem_;
+        if (threadIdx.x == 0) {
+            const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.ticket + 1 + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *tk = t;
+        }
+        __syncthreads();
+        bslot = *tk;
+        __syncthreads();
+        if (bslot < 0 || bslot >= a.n_slots) return;
+    }
     const int chain = a.chain_order ? a.chain_order[bslot] : bslot;
     // the chains of a sweep are shared out between launches by what their previous sweep looked like (pmdi_api.cpp)
     if (a.group_flag && ((int)a.group_flag[chain] != a.group_sel || bslot < a.rank_lo || bslot >= a.rank_hi)) return;
@@ -139,6 +154,10 @@ hipError_t pmdi_launch_sweep2(const SweepArgs &a_in, SweepArgs *d_args, int n_ch
     if (staging) { *staging = a; src = staging; }
     e = hipMemcpyAsync(d_args, src, sizeof(SweepArgs), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
+    if (a.ticket) {
+        e = hipMemsetAsync(a.ticket, 0, sizeof(int), stream);
+        if (e != hipSuccess) return e;
+    }
     const SweepArgs *ap = d_args;
     void *args[] = {(void *)&ap};
     e = hipLaunchKernel(fn, dim3((unsigned)n_chains), dim3(64u * (unsigned)nw), args, lds, stream);

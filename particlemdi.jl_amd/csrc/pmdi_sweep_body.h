@@ -288,6 +288,15 @@ __device__ __forceinline__ int rebuild_classes(const DualT &pidk, const ClsList 
     return (int)carry;
 }
 
+// position of this workgroup in the launch order.  In the settled-chain kernel's translation unit (PMDI_BSLOT_FROM_TICKET) this code
+// runs in that kernel's workgroup, carrying a handed-over chain on: the position is the one the workgroup DREW (SweepArgs::ticket), kept
+// under 1 + blockIdx.x.  The general kernel's own launches deal positions by blockIdx.x (a ticket there cost cfg2 6 %: one more
+// memory access in every out-of-line function of the step; profiles/README.md r04).
+#ifdef PMDI_BSLOT_FROM_TICKET
+#define PMDI_BLOCK_SLOT() (a.ticket ? __hip_atomic_load(a.ticket + 1 + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (int)blockIdx.x)
+#else
+#define PMDI_BLOCK_SLOT() ((int)blockIdx.x)
+#endif
 #define PMDI_PREAMBLE PMDI_PREAMBLE_K(false)
 #define PMDI_PREAMBLE_K(K1_)                                                                  \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                      \
@@ -296,7 +305,7 @@ __device__ __forceinline__ int rebuild_classes(const DualT &pidk, const ClsList 
     /* split mode: the K datasets of a chain are swept by K cooperating workgroups (blocks b, b+8, ... share a chain's \
        XCD under round-robin placement: speed only, the hand-off is placement-independent) */  \
     const int Kf = a.K;                                                                        \
-    const int bslot = a.ksplit ? a.slot_base + (int)((blockIdx.x / (8u * (unsigned)Kf)) * 8u + (blockIdx.x & 7u)) : (int)blockIdx.x; \
+    const int bslot = a.ksplit ? a.slot_base + (int)((blockIdx.x / (8u * (unsigned)Kf)) * 8u + (blockIdx.x & 7u)) : PMDI_BLOCK_SLOT(); \
     const int kd0 = a.ksplit ? (int)((blockIdx.x >> 3) % (unsigned)Kf) : 0;                    \
     const int chain = bslot < a.n_slots ? (a.chain_order ? a.chain_order[bslot] : bslot) : 0;  \
     const int K = ((K1_) || a.ksplit) ? 1 : a.K, N = a.N, P = a.P, cap = a.cap;                \

@@ -521,3 +521,42 @@ def test_settled_chain_kernel_hands_back_what_does_not_fit(pkg, O, monkeypatch):
     data, _ = _gauss_planted(rng, 200, 2, sep=0.5)
     g = _compare_run(pkg, O, data, ["gaussian"] * 2, 20, 1024, 2, 78, 50)
     assert g.sw.settled and g.sw.given_back()[3] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ticket", ["1", "0"])
+def test_settled_launch_positions_drawn_by_ticket(pkg, O, monkeypatch, ticket):
+    """The settled-chain launch lets a workgroup DRAW its position in the launch order (SweepArgs::ticket) instead of taking
+    blockIdx.x: more chains than workgroup slots, every chain kept on that kernel (PMDI_SETTLED=2: from the random start most of them
+    are handed over, so the general kernel's code has to find the drawn position too).  Every chain equals its single-chain oracle run
+    over several sweeps (the launch order changes with the chains' costs), with the ticket and without."""
+    monkeypatch.setenv("PMDI_SETTLED", "2")
+    monkeypatch.setenv("PMDI_KSPLIT", "0")
+    monkeypatch.setenv("PMDI_TICKET", ticket)
+    monkeypatch.setenv("PMDI_STICKY", "0")          # (a handed-over chain starts its next sweep on the settled-chain kernel again)
+    rng = np.random.default_rng(505)
+    n, N, P, K, Cn, n1 = 200, 20, 1024, 2, 700, 50
+    data, _ = _gauss_planted(rng, n, K, sep=0.5)            # (the shape of test_settled_chain_kernel_hands_back_what_does_not_fit)
+    kinds = ["gaussian"] * K
+    sw = pkg.Sweeper(data, kinds, N, P, n_chains=Cn, seed=4100)
+    assert sw.settled
+    check = [0, 1, 17, 255, 256, 511, 512, 513, 698, 699]
+    orc = {c: O.Oracle(data, kinds, N, P, seed=4100 + c) for c in check}
+    s = rng.integers(1, N + 1, size=(Cn, n, K))
+    by_all = set()
+    for it in range(1, 4):
+        order = np.stack([rng.permutation(n) + 1 for _ in range(Cn)])
+        hyp = [random_hypers(rng, N, K) for _ in range(Cn)]
+        r = sw.sweep(it, s, order, n1, np.stack([h[0] for h in hyp]), np.stack([h[1] for h in hyp]))
+        by = sw.swept_by()
+        assert set(by.tolist()) <= {1, 2}
+        by_all |= set(by.tolist())
+        for c in check:
+            o = orc[c].sweep(it, s[c], order[c], n1, hyp[c][0], hyp[c][1])
+            assert (r["s"][c] == o["s"]).all() and int(r["p_star"][c]) == o["p_star"], (it, c)
+            for key in ("n_operations", "n_resamples", "n_clones", "max_id", "sum_classes"):
+                assert r["stats"][c][key] == o["stats"][key], (it, c, key)
+        # the chains that are not compared one by one: every one swept, none twice (allocations in range, no error reported)
+        assert (r["s"] >= 1).all() and (r["s"] <= N).all()
+        s = r["s"].copy()
+    assert by_all == {1, 2}, by_all
