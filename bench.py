@@ -479,7 +479,7 @@ def main():
             issue = {"issue_slots_busy_frac": fr["SQ_ACTIVE_INST_ANY"], "valu_frac": fr["SQ_ACTIVE_INST_VALU"], "scalar_frac": fr["SQ_ACTIVE_INST_SCA"],
                      "lds_frac": fr["SQ_ACTIVE_INST_LDS"], "wait_frac": fr["SQ_WAIT_ANY"], "waves_per_simd": 2,
                      "instructions_per_wave_and_observation": mj["instructions_per_wave_and_observation"],
-                     "source": "profiles/r04/pmc_instruction_mix.json (rocprofv3 --pmc, two passes, the settled-chain kernel's dispatch of a 1 024-chain sweep): "
+                     "source": "profiles/r04/pmc_instruction_mix.json (rocprofv3 --pmc, two passes, the settled-chain kernel's dispatch of a 512-chain sweep of the final tree): "
                                "fractions of SQ_WAVE_CYCLES"}
         out = {
             "metric": "Gibbs iters/sec (and obs·particles/sec) at 1/2/4/8 GPUs vs CPU ref",
